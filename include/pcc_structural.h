@@ -1,0 +1,105 @@
+/*
+ * pcc_structural.h -- C ABI of libpcc_structural.so (MI355X / gfx950 structural-loss kernels).
+ *
+ * Drop-in boundary for the native half of the reference's `structural_losses` package: the five
+ * launchers declared at external/pytorch_structural_losses/src/structural_loss.cpp:10-14 and
+ * defined in nndistance.cu:125-128,149-154 and approxmatch.cu:299-326 of the reference.  Same names,
+ * same argument order and meaning; the only change is `cudaStream_t` -> `hipStream_t` (passed as
+ * `void *` so that the header needs no HIP include).  All pointers are device pointers to
+ * contiguous row-major float32 / int32 arrays; inputs are borrowed and never written; outputs are
+ * fully overwritten.  Calls enqueue work on `stream` and return without synchronising.
+ *
+ * Error behaviour: the reference's approxmatch/matchcost/matchcostgrad launchers throw
+ * std::runtime_error("CUDA kernel failed : <code>") (approxmatch.cu:303-306) and its nndistance
+ * launchers check nothing.  A C ABI cannot throw, so every `pcc_*` entry returns an int
+ * (0 = success, otherwise the hipError_t of the failed launch / a PCC_E* code) and records a message
+ * retrievable with pcc_last_error(); the reference-named void launchers record the same message and
+ * the host-side binding raises RuntimeError("HIP kernel failed : <code>") from it.
+ */
+#ifndef PCC_STRUCTURAL_H
+#define PCC_STRUCTURAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default) /* the library is built -fvisibility=hidden; only this ABI is exported */
+
+typedef void *pcc_stream_t; /* hipStream_t */
+
+#define PCC_OK 0
+#define PCC_EINVAL (-22)  /* bad sizes / null pointers */
+#define PCC_ENOMEM (-12)  /* workspace allocation failed */
+
+/* ---- library info ------------------------------------------------------------------------- */
+const char *pcc_version(void);
+/* Message of the last failed call on this thread ("" if none). */
+const char *pcc_last_error(void);
+/* Status of the last reference-named (void) launcher call on this thread; reset to 0 by each call. */
+int pcc_last_status(void);
+
+/* ---- Chamfer nearest neighbour ---------------------------------------------------------------
+ * Replaces `nndistance` (reference nndistance.cu:125-128; declared structural_loss.cpp:13).
+ *   xyz[b,n,3], xyz2[b,m,3] -> result[b,n] = min_k |xyz_j - xyz2_k|^2, result_i[b,n] = argmin
+ *   (lowest index on ties), and the same with roles swapped -> result2[b,m], result2_i[b,m].
+ * Distances are evaluated as fmaf(dz,dz, fmaf(dx,dx, dy*dy)) on differences (bit-exact vs oracle). */
+void nndistance(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
+                float *result2, int *result2_i, pcc_stream_t stream);
+int pcc_nndistance(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
+                   float *result2, int *result2_i, pcc_stream_t stream);
+
+/* Replaces `nndistancegrad` (reference nndistance.cu:149-154; declared structural_loss.cpp:14).
+ *   grad_xyz1[b,n,3] = 2 g1_j (p1_j - p2_{idx1_j}) + sum_{k: idx2_k = j} 2 g2_k (p1_j - p2_k), and
+ *   symmetrically grad_xyz2[b,m,3].  Outputs are overwritten (no prior memset needed). */
+void nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad_dist1,
+                    const int *idx1, const float *grad_dist2, const int *idx2, float *grad_xyz1,
+                    float *grad_xyz2, pcc_stream_t stream);
+int pcc_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad_dist1,
+                       const int *idx1, const float *grad_dist2, const int *idx2, float *grad_xyz1,
+                       float *grad_xyz2, pcc_stream_t stream);
+
+/* ---- approximate EMD ---------------------------------------------------------------------------
+ * Replaces `approxmatch` (reference approxmatch.cu:299-307; declared structural_loss.cpp:10).
+ *   xyz1[b,n,3], xyz2[b,m,3] -> match[b,m,n] (query-major), temp[b,2(n+m)] =
+ *   [remainL(n) | remainR(m) | ratioL(n) | ratioR(m)] after the last level.
+ * The reference-named form allocates its per-level workspace with hipMallocAsync on `stream`;
+ * pcc_approxmatch_ws takes a caller-provided workspace of pcc_approxmatch_workspace_bytes(b,n,m)
+ * bytes instead (graph-capture friendly, no allocation in the call). */
+void approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                 pcc_stream_t stream);
+int pcc_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                    pcc_stream_t stream);
+size_t pcc_approxmatch_workspace_bytes(int b, int n, int m);
+int pcc_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                       void *workspace, size_t workspace_bytes, pcc_stream_t stream);
+
+/* approxmatch + matchcost in one call (what the Python-level match_cost forward needs,
+ * reference structural_losses/match_cost.py:25-27): the pass that materialises `match` also
+ * accumulates cost[b], so `match` is not re-read.  Same results as pcc_approxmatch + pcc_matchcost up to
+ * float summation order. */
+int pcc_approxmatch_cost(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                         float *cost, pcc_stream_t stream);
+
+/* Replaces `matchcost` (reference approxmatch.cu:309-316; declared structural_loss.cpp:11).
+ *   out[b] = sum_{k<m} sum_{j<n} match[b,k,j] * sqrt(|xyz1_j - xyz2_k|^2).  `match` is read-only
+ *   (the reference declares it non-const but never writes it). */
+void matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *out,
+               pcc_stream_t stream);
+int pcc_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *out,
+                  pcc_stream_t stream);
+
+/* Replaces `matchcostgrad` (reference approxmatch.cu:318-326; declared structural_loss.cpp:12).
+ *   grad1[b,l,:] = sum_k match[b,k,l] (p1_l - p2_k) rsqrt(max(d2,1e-20));
+ *   grad2[b,k,:] = sum_j match[b,k,j] (p2_k - p1_j) rsqrt(max(d2,1e-20)). */
+void matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                   float *grad1, float *grad2, pcc_stream_t stream);
+int pcc_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                      float *grad1, float *grad2, pcc_stream_t stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCC_STRUCTURAL_H */

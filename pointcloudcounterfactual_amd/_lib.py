@@ -1,0 +1,61 @@
+"""ctypes binding of ``libpcc_structural.so`` (the C ABI declared in ``include/pcc_structural.h``).
+
+The library is hand-written HIP for gfx950; there is no CPU or PyTorch fallback.  If the shared
+object has not been built (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C pointcloudcounterfactual_amd/csrc``) importing this module raises ``ImportError``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpcc_structural.so')
+
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+
+# name -> (restype, argtypes); must list every symbol include/pcc_structural.h declares.
+ABI: dict[str, tuple[object, list[object]]] = {
+    'pcc_version': (ctypes.c_char_p, []),
+    'pcc_last_error': (ctypes.c_char_p, []),
+    'pcc_last_status': (_int, []),
+    'nndistance': (None, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_nndistance': (_int, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'nndistancegrad': (None, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_nndistancegrad': (_int, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'approxmatch': (None, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_approxmatch': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_approxmatch_workspace_bytes': (ctypes.c_size_t, [_int, _int, _int]),
+    'pcc_approxmatch_ws': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    'pcc_approxmatch_cost': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'matchcost': (None, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_matchcost': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    'matchcostgrad': (None, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_matchcostgrad': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: the HIP extension has not been built '
+            '(run `make -C pointcloudcounterfactual_amd/csrc`); there is no fallback path.'
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in ABI.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int, what: str) -> None:
+    """Raise the error the reference raises from its launchers (approxmatch.cu:303-306)."""
+    if status != 0:
+        msg = lib.pcc_last_error().decode() or f'HIP kernel failed : {status}'
+        raise RuntimeError(f'{what}: {msg}')

@@ -1,0 +1,148 @@
+"""Host-side mirror of the reference's ``structural_losses.structural_losses_backend`` pybind module
+(``external/pytorch_structural_losses/src/structural_loss.cpp:24-135``): the same five functions, the
+same argument meaning, output shapes/dtypes, ownership (fresh ``torch.empty`` outputs) and error
+behaviour (``RuntimeError`` when an input is not a contiguous accelerator tensor), enqueuing on the
+current stream without synchronising.  The arithmetic is the C-ABI library's HIP kernels; PyTorch is
+only used for device memory and the stream handle.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from pointcloudcounterfactual_amd import _lib
+
+_L = _lib.lib
+
+
+def _check_input(x: torch.Tensor, name: str) -> None:
+    # CHECK_INPUT, structural_loss.cpp:6-8
+    if not x.device.type == 'cuda':
+        raise RuntimeError(f'{name} must be a CUDA tensor')
+    if not x.is_contiguous():
+        raise RuntimeError(f'{name} must be contiguous')
+
+
+def _f32(x: torch.Tensor, name: str) -> None:
+    # the reference's data_ptr<float>() throws for any other dtype
+    if x.dtype != torch.float32:
+        raise RuntimeError(f'expected scalar type Float but found {x.dtype} ({name})')
+
+
+def _i32(x: torch.Tensor, name: str) -> None:
+    if x.dtype != torch.int32:
+        raise RuntimeError(f'expected scalar type Int but found {x.dtype} ({name})')
+
+
+def _stream(x: torch.Tensor) -> int:
+    return torch.cuda.current_stream(x.device).cuda_stream
+
+
+def _sizes(set_d: torch.Tensor, set_q: torch.Tensor) -> tuple[int, int, int]:
+    return set_d.size(0), set_d.size(1), set_q.size(1)
+
+
+def ApproxMatch(set_d: torch.Tensor, set_q: torch.Tensor) -> list[torch.Tensor]:
+    """-> [match[B,M,N], temp[B,2(N+M)]]   (structural_loss.cpp:24-38)."""
+    b, n, m = _sizes(set_d, set_q)
+    match = torch.empty((b, m, n), dtype=torch.float32, device=set_d.device)
+    temp = torch.empty((b, (n + m) * 2), dtype=torch.float32, device=set_d.device)
+    _check_input(set_d, 'set_d')
+    _check_input(set_q, 'set_q')
+    _f32(set_d, 'set_d')
+    _f32(set_q, 'set_q')
+    with torch.cuda.device(set_d.device):
+        _lib.check(_L.pcc_approxmatch(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
+                                      temp.data_ptr(), _stream(set_d)), 'ApproxMatch')
+    return [match, temp]
+
+
+def ApproxMatchCost(set_d: torch.Tensor, set_q: torch.Tensor) -> list[torch.Tensor]:
+    """ApproxMatch + MatchCost in one pass over ``match`` -> [match, temp, cost[B]] (extension)."""
+    b, n, m = _sizes(set_d, set_q)
+    match = torch.empty((b, m, n), dtype=torch.float32, device=set_d.device)
+    temp = torch.empty((b, (n + m) * 2), dtype=torch.float32, device=set_d.device)
+    cost = torch.empty((b,), dtype=torch.float32, device=set_d.device)
+    _check_input(set_d, 'set_d')
+    _check_input(set_q, 'set_q')
+    _f32(set_d, 'set_d')
+    _f32(set_q, 'set_q')
+    with torch.cuda.device(set_d.device):
+        _lib.check(_L.pcc_approxmatch_cost(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
+                                           temp.data_ptr(), cost.data_ptr(), _stream(set_d)), 'ApproxMatchCost')
+    return [match, temp, cost]
+
+
+def MatchCost(set_d: torch.Tensor, set_q: torch.Tensor, match: torch.Tensor) -> torch.Tensor:
+    """-> cost[B]   (structural_loss.cpp:40-53)."""
+    b, n, m = _sizes(set_d, set_q)
+    out = torch.empty((b,), dtype=torch.float32, device=set_d.device)
+    _check_input(set_d, 'set_d')
+    _check_input(set_q, 'set_q')
+    _check_input(match, 'match')
+    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (match, 'match')):
+        _f32(t, name)
+    if match.numel() != b * n * m:
+        raise RuntimeError(f'match has {match.numel()} elements, expected {b}x{m}x{n}')
+    with torch.cuda.device(set_d.device):
+        _lib.check(_L.pcc_matchcost(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(), out.data_ptr(),
+                                    _stream(set_d)), 'MatchCost')
+    return out
+
+
+def MatchCostGrad(set_d: torch.Tensor, set_q: torch.Tensor, match: torch.Tensor) -> list[torch.Tensor]:
+    """-> [grad1[B,N,3], grad2[B,M,3]]   (structural_loss.cpp:55-70)."""
+    b, n, m = _sizes(set_d, set_q)
+    grad1 = torch.empty((b, n, 3), dtype=torch.float32, device=set_d.device)
+    grad2 = torch.empty((b, m, 3), dtype=torch.float32, device=set_d.device)
+    _check_input(set_d, 'set_d')
+    _check_input(set_q, 'set_q')
+    _check_input(match, 'match')
+    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (match, 'match')):
+        _f32(t, name)
+    if match.numel() != b * n * m:
+        raise RuntimeError(f'match has {match.numel()} elements, expected {b}x{m}x{n}')
+    with torch.cuda.device(set_d.device):
+        _lib.check(_L.pcc_matchcostgrad(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
+                                        grad1.data_ptr(), grad2.data_ptr(), _stream(set_d)), 'MatchCostGrad')
+    return [grad1, grad2]
+
+
+def NNDistance(set_d: torch.Tensor, set_q: torch.Tensor) -> list[torch.Tensor]:
+    """-> [dist1[B,N] f32, idx1[B,N] i32, dist2[B,M] f32, idx2[B,M] i32]   (structural_loss.cpp:81-100)."""
+    b, n, m = _sizes(set_d, set_q)
+    dev = set_d.device
+    dist1 = torch.empty((b, n), dtype=torch.float32, device=dev)
+    idx1 = torch.empty((b, n), dtype=torch.int32, device=dev)
+    dist2 = torch.empty((b, m), dtype=torch.float32, device=dev)
+    idx2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+    _check_input(set_d, 'set_d')
+    _check_input(set_q, 'set_q')
+    _f32(set_d, 'set_d')
+    _f32(set_q, 'set_q')
+    with torch.cuda.device(dev):
+        _lib.check(_L.pcc_nndistance(b, n, set_d.data_ptr(), m, set_q.data_ptr(), dist1.data_ptr(), idx1.data_ptr(),
+                                     dist2.data_ptr(), idx2.data_ptr(), _stream(set_d)), 'NNDistance')
+    return [dist1, idx1, dist2, idx2]
+
+
+def NNDistanceGrad(set_d: torch.Tensor, set_q: torch.Tensor, idx1: torch.Tensor, idx2: torch.Tensor,
+                   grad_dist1: torch.Tensor, grad_dist2: torch.Tensor) -> list[torch.Tensor]:
+    """-> [grad1[B,N,3], grad2[B,M,3]]   (structural_loss.cpp:102-125)."""
+    b, n, m = _sizes(set_d, set_q)
+    grad1 = torch.empty((b, n, 3), dtype=torch.float32, device=set_d.device)
+    grad2 = torch.empty((b, m, 3), dtype=torch.float32, device=set_d.device)
+    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (idx1, 'idx1'), (idx2, 'idx2'),
+                    (grad_dist1, 'grad_dist1'), (grad_dist2, 'grad_dist2')):
+        _check_input(t, name)
+    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (grad_dist1, 'grad_dist1'), (grad_dist2, 'grad_dist2')):
+        _f32(t, name)
+    _i32(idx1, 'idx1')
+    _i32(idx2, 'idx2')
+    if idx1.numel() != b * n or grad_dist1.numel() != b * n or idx2.numel() != b * m or grad_dist2.numel() != b * m:
+        raise RuntimeError('NNDistanceGrad: idx/grad_dist shapes do not match the clouds')
+    with torch.cuda.device(set_d.device):
+        _lib.check(_L.pcc_nndistancegrad(b, n, set_d.data_ptr(), m, set_q.data_ptr(), grad_dist1.data_ptr(),
+                                         idx1.data_ptr(), grad_dist2.data_ptr(), idx2.data_ptr(), grad1.data_ptr(),
+                                         grad2.data_ptr(), _stream(set_d)), 'NNDistanceGrad')
+    return [grad1, grad2]

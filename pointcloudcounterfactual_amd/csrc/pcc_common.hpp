@@ -1,0 +1,43 @@
+// Shared host/device helpers for libpcc_structural.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "pcc_structural.h"
+
+namespace pcc {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// Per-thread last-error record behind pcc_last_error() / pcc_last_status().
+void set_error(int status, const char *what);
+void clear_error();
+
+inline int check_launch(const char *what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "HIP kernel failed : %d (%s) in %s", (int)err, hipGetErrorString(err), what);
+        set_error((int)err, buf);
+        return (int)err;
+    }
+    return PCC_OK;
+}
+
+inline int invalid(const char *what) {
+    set_error(PCC_EINVAL, what);
+    return PCC_EINVAL;
+}
+
+// Squared norm of a difference vector, in the one rounding order shared with the CPU oracle
+// (oracle/structural_oracle.c sqsum3 mode 0).  The translation unit is built with
+// -ffp-contract=off, so `y * y` stays a rounded multiply and nothing else is fused.
+__device__ __forceinline__ float sq3(float x, float y, float z) {
+    return __builtin_fmaf(z, z, __builtin_fmaf(x, x, y * y));
+}
+
+__host__ __device__ constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace pcc

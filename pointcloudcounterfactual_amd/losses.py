@@ -1,0 +1,105 @@
+"""Autograd surface of the structural losses.
+
+``nn_distance`` / ``match_cost`` keep the reference's signatures and autograd behaviour
+(``external/pytorch_structural_losses/structural_losses/nn_distance.py:9-43``,
+``.../match_cost.py:11-50``); ``chamfer`` is the Chamfer loss the reference's GPU training path
+computes with PyKeOps (``src/train/metrics_and_losses.py:21-41``), expressed through ``nn_distance``
+(SURVEY.md section 8 row A7); ``torch_chamfer`` is the reference's CPU Chamfer (``:44-47``).
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import torch
+from torch.autograd import Function
+
+from pointcloudcounterfactual_amd import backend
+
+
+class NNDistanceFunction(Function):
+    """``(set1[B,N,3], set2[B,M,3]) -> (dist1[B,N], dist2[B,M])`` squared nearest-neighbour distances."""
+
+    @staticmethod
+    def forward(ctx: Any, *args: Any, **kwargs: Any) -> Any:
+        set1, set2, *_ = args
+        ctx.save_for_backward(set1, set2)
+        dist1, idx1, dist2, idx2 = backend.NNDistance(set1, set2)
+        ctx.idx1 = idx1  # indices are constants of the backward pass (nn_distance.py:22-24)
+        ctx.idx2 = idx2
+        return dist1, dist2
+
+    @staticmethod
+    def backward(ctx: Any, *grad_outputs: Any) -> Any:
+        set1, set2 = ctx.saved_tensors
+        grad1, grad2 = backend.NNDistanceGrad(
+            set1, set2, ctx.idx1, ctx.idx2, grad_outputs[0].contiguous(), grad_outputs[1].contiguous()
+        )
+        return grad1, grad2
+
+
+class MatchCostFunction(Function):
+    """``(set1[B,N,3], set2[B,M,3]) -> cost[B]`` approximate earth mover's distance."""
+
+    # One pass materialises ``match`` and accumulates the cost (pcc_approxmatch_cost); set to False to
+    # run the reference's two backend calls ApproxMatch -> MatchCost (match_cost.py:25-27) instead.
+    fused_forward = True
+
+    @staticmethod
+    def forward(ctx: Any, *args: torch.Tensor, **kwargs: Any) -> torch.Tensor:
+        set1, set2, *_ = args
+        ctx.save_for_backward(set1, set2)
+        if MatchCostFunction.fused_forward:
+            match, _temp, cost = backend.ApproxMatchCost(set1, set2)
+        else:
+            match, _temp = backend.ApproxMatch(set1, set2)
+            cost = backend.MatchCost(set1, set2, match)
+        ctx.match = match  # kept alive until backward, as the reference does (match_cost.py:26)
+        return cost
+
+    @staticmethod
+    def backward(ctx: Any, *grad_outputs: Any) -> tuple[torch.Tensor, torch.Tensor]:
+        grad_output = grad_outputs[0]
+        set1, set2 = ctx.saved_tensors
+        grad1, grad2 = backend.MatchCostGrad(set1, set2, ctx.match)
+        scale = grad_output.unsqueeze(1).unsqueeze(2)
+        return grad1 * scale, grad2 * scale
+
+    @classmethod
+    def apply(cls, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
+        return super().apply(x, y)  # type: ignore[return-value]
+
+
+nn_distance = NNDistanceFunction.apply
+match_cost = MatchCostFunction.apply
+
+
+def chamfer(t1: torch.Tensor, t2: torch.Tensor, reduction: str = 'mean') -> torch.Tensor:
+    """Chamfer loss ``[B]`` on the accelerator.
+
+    ``reduction='mean'`` reproduces ``pykeops_chamfer`` (metrics_and_losses.py:21-41):
+    ``dist2.mean(1) + dist1.mean(1)``; ``'sum'`` reproduces the scale of ``torch_chamfer`` (:44-47).
+    Gradients flow through the gathered nearest neighbours only (indices are constants), as in both.
+    """
+    dist1, dist2 = nn_distance(t1, t2)
+    if reduction == 'mean':
+        return dist2.mean(1) + dist1.mean(1)
+    if reduction == 'sum':
+        return dist1.sum(1) + dist2.sum(1)
+    raise ValueError(f"reduction must be 'mean' or 'sum', got {reduction!r}")
+
+
+def torch_square_distance(t1: torch.Tensor, t2: torch.Tensor) -> torch.Tensor:
+    """Expanded-form squared distances ``[B,N,M]`` (reference ``src/utils/neighbour_ops.py:43-50``)."""
+    t2 = t2.transpose(-1, -2)
+    dist = -2 * torch.matmul(t1, t2)
+    dist += torch.sum(t1**2, -1, keepdim=True)
+    dist += torch.sum(t2**2, -2, keepdim=True)
+    return dist
+
+
+def torch_chamfer(t1: torch.Tensor, t2: torch.Tensor) -> torch.Tensor:
+    """The reference's CPU Chamfer (sum over points; ``metrics_and_losses.py:44-47``).  This is the
+    reference's own host path for ``user.cpu`` runs (BASELINE config 1), not a fallback of ``chamfer``."""
+    dist = torch_square_distance(t1, t2)
+    return torch.min(dist, dim=-1)[0].sum(1) + torch.min(dist, dim=-2)[0].sum(1)

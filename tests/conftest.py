@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'reference: needs /root/reference (container only; skipped elsewhere)')
+
+
+@pytest.fixture(scope='session')
+def oracle_mod():
+    import oracle
+
+    oracle.build()
+    oracle.set_threads(min(8, oracle.max_threads()))
+    return oracle
+
+
+@pytest.fixture(scope='session')
+def cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')

@@ -1,0 +1,207 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): nearest-neighbour indices and squared distances bit-exact;
+float results of the EMD path within the tolerance written next to each assert.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import pair
+
+pytestmark = pytest.mark.gpu
+
+NN_SHAPES = [(1, 1, 1), (2, 3, 5), (1, 7, 1), (2, 64, 64), (3, 257, 130), (2, 512, 513), (2, 1024, 1024),
+             (1, 2049, 2047), (2, 100, 4100), (4, 1024, 1024)]
+
+
+def _dev(x, cuda):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(cuda)
+
+
+@pytest.mark.parametrize('b,n,m', NN_SHAPES)
+@pytest.mark.parametrize('kind', ['recon', 'uniform'])
+def test_nndistance_bit_exact(cuda, oracle_mod, b, n, m, kind):
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(100 + n + m, b, n, m, kind)
+    d1, i1, d2, i2 = backend.NNDistance(_dev(a, cuda), _dev(c, cuda))
+    od1, oi1, od2, oi2 = oracle_mod.nndistance(a, c)
+    assert np.array_equal(i1.cpu().numpy(), oi1)
+    assert np.array_equal(i2.cpu().numpy(), oi2)
+    assert np.array_equal(d1.cpu().numpy(), od1)  # bit-exact f32
+    assert np.array_equal(d2.cpu().numpy(), od2)
+
+
+def test_nndistance_ties_lowest_index(cuda, oracle_mod):
+    """Duplicate candidates: the lowest index must win (nndistance.cu:26,36,116)."""
+    from pointcloudcounterfactual_amd import backend
+
+    rng = np.random.default_rng(5)
+    base = rng.random((2, 40, 3), dtype=np.float32)
+    c = np.concatenate([base] * 30, axis=1)  # 1200 candidates, every point repeated 30x, spans chunks/waves
+    a = base[:, ::-1].copy()
+    d1, i1, d2, i2 = backend.NNDistance(_dev(a, cuda), _dev(c, cuda))
+    od1, oi1, od2, oi2 = oracle_mod.nndistance(a, c)
+    assert np.array_equal(i1.cpu().numpy(), oi1) and np.array_equal(i2.cpu().numpy(), oi2)
+    assert (i1.cpu().numpy() < 40).all()
+    assert np.array_equal(d1.cpu().numpy(), od1) and np.array_equal(d2.cpu().numpy(), od2)
+
+
+def test_nndistance_self(cuda):
+    from pointcloudcounterfactual_amd import backend
+
+    a, _ = pair(9, 2, 777, 777, 'uniform')
+    t = _dev(a, cuda)
+    d1, i1, d2, i2 = backend.NNDistance(t, t)
+    assert (d1 == 0).all() and (d2 == 0).all()
+    ar = torch.arange(777, device=cuda, dtype=torch.int32).expand(2, -1)
+    assert torch.equal(i1, ar) and torch.equal(i2, ar)
+
+
+@pytest.mark.parametrize('b,n,m', [(2, 3, 5), (3, 257, 130), (2, 1024, 1024), (1, 2049, 2047)])
+def test_nndistancegrad(cuda, oracle_mod, b, n, m):
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(200 + n, b, n, m)
+    rng = np.random.default_rng(1)
+    g1 = rng.standard_normal((b, n)).astype(np.float32)
+    g2 = rng.standard_normal((b, m)).astype(np.float32)
+    _, oi1, _, oi2 = oracle_mod.nndistance(a, c)
+    og1, og2 = oracle_mod.nndistancegrad(a, c, oi1, oi2, g1, g2)
+    r1, r2 = backend.NNDistanceGrad(_dev(a, cuda), _dev(c, cuda), _dev(oi1, cuda), _dev(oi2, cuda), _dev(g1, cuda),
+                                    _dev(g2, cuda))
+    # scatter-add order differs (reference: unordered atomics) -> 1e-5 relative, small absolute floor
+    np.testing.assert_allclose(r1.cpu().numpy(), og1, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r2.cpu().numpy(), og2, rtol=1e-5, atol=1e-6)
+
+
+def test_nn_distance_autograd_matches_torch(cuda):
+    """Autograd through nn_distance == autograd through a dense torch fp32 evaluation of the same loss."""
+    from structural_losses import nn_distance
+
+    a, c = pair(11, 2, 300, 200)
+    t1 = _dev(a, cuda).requires_grad_(True)
+    t2 = _dev(c, cuda).requires_grad_(True)
+    d1, d2 = nn_distance(t1, t2)
+    (d1.mean(1) + d2.mean(1)).sum().backward()
+    u1 = _dev(a, cuda).requires_grad_(True)
+    u2 = _dev(c, cuda).requires_grad_(True)
+    D = ((u1[:, :, None, :] - u2[:, None, :, :]) ** 2).sum(-1)
+    (D.min(2)[0].mean(1) + D.min(1)[0].mean(1)).sum().backward()
+    np.testing.assert_allclose(t1.grad.cpu().numpy(), u1.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(t2.grad.cpu().numpy(), u2.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+AM_SHAPES = [(1, 1, 1), (2, 3, 5), (2, 64, 64), (2, 257, 130), (2, 128, 256), (1, 513, 512), (2, 1024, 1024)]
+
+
+@pytest.mark.parametrize('b,n,m', AM_SHAPES)
+@pytest.mark.parametrize('kind', ['recon', 'uniform'])
+def test_approxmatch_vs_oracle(cuda, oracle_mod, b, n, m, kind):
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(300 + n + m, b, n, m, kind)
+    match, temp = backend.ApproxMatch(_dev(a, cuda), _dev(c, cuda))
+    om, ot = oracle_mod.approxmatch(a, c)
+    om64, _ = oracle_mod.approxmatch_f64(a, c)
+    got = match.cpu().numpy()
+    # The f32 recurrence is ill-conditioned element-wise (remain* are clamped differences): the f32 oracle
+    # itself sits up to ~1e-4 (abs) from the float64 recurrence.  Bar: we are as close to the float64
+    # recurrence as the f32 oracle is (x4 slack), and row/column masses agree to 1e-5 relative.
+    err_oracle = np.abs(om - om64).max()
+    err_ours = np.abs(got - om64).max()
+    assert err_ours <= max(4 * err_oracle, 5e-5), (err_ours, err_oracle)
+    np.testing.assert_allclose(got.sum(1), om64.sum(1), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got.sum(2), om64.sum(2), rtol=1e-4, atol=1e-5)
+    # cost: 1e-5 relative against the float64 recurrence's cost (north_star tolerance)
+    cost = backend.MatchCost(_dev(a, cuda), _dev(c, cuda), match).cpu().numpy()
+    oc64 = oracle_mod.matchcost_f64(a, c, om64)
+    oc32 = oracle_mod.matchcost(a, c, om)
+    tol = max(1e-5, 4 * np.abs(oc32 - oc64).max() / max(np.abs(oc64).max(), 1e-30))
+    np.testing.assert_allclose(cost, oc64, rtol=tol, atol=1e-7)
+
+
+@pytest.mark.parametrize('b,n,m', [(2, 3, 5), (2, 257, 130), (2, 1024, 1024), (1, 100, 2100)])
+def test_matchcost_and_grad_given_match(cuda, oracle_mod, b, n, m):
+    """MatchCost / MatchCostGrad on the ORACLE's match: isolates these kernels from the recurrence."""
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(400 + n, b, n, m)
+    om, _ = oracle_mod.approxmatch(a, c)
+    t1, t2, tm = _dev(a, cuda), _dev(c, cuda), _dev(om, cuda)
+    cost = backend.MatchCost(t1, t2, tm).cpu().numpy()
+    oc64 = oracle_mod.matchcost_f64(a, c, om.astype(np.float64))
+    np.testing.assert_allclose(cost, oc64, rtol=1e-5)
+    g1, g2 = backend.MatchCostGrad(t1, t2, tm)
+    h1, h2 = oracle_mod.matchcostgrad_f64(a, c, om.astype(np.float64))
+    scale = max(np.abs(h1).max(), np.abs(h2).max())
+    np.testing.assert_allclose(g1.cpu().numpy(), h1, rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(g2.cpu().numpy(), h2, rtol=1e-5, atol=1e-5 * scale)
+
+
+def test_match_cost_fused_equals_two_step(cuda):
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(17, 3, 500, 384)
+    t1, t2 = _dev(a, cuda), _dev(c, cuda)
+    match, temp = backend.ApproxMatch(t1, t2)
+    cost = backend.MatchCost(t1, t2, match)
+    match2, temp2, cost2 = backend.ApproxMatchCost(t1, t2)
+    assert torch.equal(match, match2) and torch.equal(temp, temp2)
+    np.testing.assert_allclose(cost2.cpu().numpy(), cost.cpu().numpy(), rtol=1e-5)
+
+
+def test_approxmatch_known_answers(cuda):
+    """n=m=1 at distance r: match=1, cost=r, grad1=(p1-p2)/r."""
+    from structural_losses import match_cost
+
+    p = torch.tensor([[[0.0, 0.0, 0.0]]], device=cuda, requires_grad=True)
+    q = torch.tensor([[[0.3, 0.4, 0.0]]], device=cuda, requires_grad=True)
+    cost = match_cost(p, q)
+    cost.sum().backward()
+    np.testing.assert_allclose(cost.item(), 0.5, rtol=1e-6)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), [[[-0.6, -0.8, 0.0]]], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(q.grad.cpu().numpy(), [[[0.6, 0.8, 0.0]]], rtol=1e-5, atol=1e-7)
+
+
+def test_backend_input_checks(cuda):
+    from pointcloudcounterfactual_amd import backend
+
+    x = torch.zeros(1, 4, 3)
+    with pytest.raises(RuntimeError, match='must be a CUDA tensor'):
+        backend.NNDistance(x, x)
+    y = torch.zeros(1, 3, 4, device=cuda).transpose(1, 2)
+    with pytest.raises(RuntimeError, match='must be contiguous'):
+        backend.ApproxMatch(y, y)
+
+
+@pytest.mark.parametrize('kind', ['recon', 'uniform'])
+def test_full_size_properties(cuda, kind):
+    """BASELINE config 2/3 sizes (B=32, N=2048): size-independent properties instead of the oracle."""
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(1234 + 2, 32, 2048, 2048, kind)
+    t1, t2 = _dev(a, cuda), _dev(c, cuda)
+    d1, i1, d2, i2 = backend.NNDistance(t1, t2)
+    # gather check: returned distance == distance to the returned index (exact), and no candidate is closer
+    g = torch.gather(t2, 1, i1.long()[..., None].expand(-1, -1, 3))
+    assert torch.equal(((g - t1) ** 2).sum(-1) >= 0, torch.ones_like(d1, dtype=torch.bool))
+    D = torch.cdist(t1.double(), t2.double()) ** 2
+    assert (D.min(2)[0] - d1.double()).abs().max() < 1e-6
+    assert (D.min(1)[0] - d2.double()).abs().max() < 1e-6
+    # permutation equivariance of the argmin
+    perm = torch.randperm(2048, device=cuda)
+    e1, j1, e2, j2 = backend.NNDistance(t1[:, perm].contiguous(), t2)
+    assert torch.equal(e1, d1[:, perm]) and torch.equal(j1, i1[:, perm])
+    assert torch.equal(e2, d2)
+    # approximate EMD: mass conservation (row mass <= multiR=1, column mass <= multiL=1), total mass ~ N
+    match, temp = backend.ApproxMatch(t1, t2)
+    assert match.min() >= 0
+    assert match.sum(1).max() <= 1 + 1e-5 and match.sum(2).max() <= 1 + 1e-5
+    assert (match.sum((1, 2)) > 2048 * 0.98).all()
+    cost = backend.MatchCost(t1, t2, match)
+    # cost is bounded below by the nearest-neighbour transport and above by mass * diameter
+    lower = 0.5 * (d1.sqrt().sum(1) + d2.sqrt().sum(1)) * 0.98
+    assert (cost >= lower * 0.99).all() and (cost <= 2048 * 2.0).all()
