@@ -498,14 +498,49 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(int rs, size_t per_s
 }
 
 // ---- host side -------------------------------------------------------------------------------------
-constexpr int kPhR = 4, kPhS = 4, kPhCH = 2048;
+constexpr int kPhCH = 2048;
+
+// Workgroup shape: R owners per lane x S candidate slices (waves).  One wave can issue a VALU
+// instruction only every 4 cycles while a SIMD retires one every 2, so a phase needs >= 2 (better 4)
+// waves per SIMD = 2048-4096 waves on 256 CUs; R is spent only once the chip is full (each LDS
+// broadcast read is then amortised over R owners).
+static int phase_cfg_override() {
+    static const int v = [] {
+        const char *e = std::getenv("PCC_AM_CFG");
+        return e ? std::atoi(e) : 0;
+    }();
+    return v;
+}
+
+template <int MODE, int R, int S>
+int launch_phase_rs(PhaseArgs a, int b, hipStream_t st, const char *what) {
+    a.tiles = pcc::ceil_div(a.n_own, 64 * R);
+    const long long grid = (long long)b * a.tiles;
+    if (grid > 0x7fffffffLL) return pcc::invalid("approxmatch: grid too large");
+    hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH>), dim3((unsigned)grid), dim3(64 * S), 0, st, a);
+    return pcc::check_launch(what);
+}
 
 template <int MODE>
 int launch_phase(const PhaseArgs &a, int b, hipStream_t st, const char *what) {
-    const long long grid = (long long)b * a.tiles;
-    if (grid > 0x7fffffffLL) return pcc::invalid("approxmatch: grid too large");
-    hipLaunchKernelGGL((am_phase_kernel<MODE, kPhR, kPhS, kPhCH>), dim3((unsigned)grid), dim3(64 * kPhS), 0, st, a);
-    return pcc::check_launch(what);
+    int cfg = phase_cfg_override();
+    if (cfg == 0) {
+        const long long owners = (long long)b * a.n_own;
+        // waves = owners / (64 R) * S ; aim for >= 4096
+        if (owners >= 4LL * 65536) cfg = 44;
+        else if (owners >= 2LL * 65536) cfg = 48;
+        else if (owners >= 65536) cfg = 28;
+        else cfg = 18;
+    }
+    switch (cfg) {
+    case 44: return launch_phase_rs<MODE, 4, 4>(a, b, st, what);
+    case 48: return launch_phase_rs<MODE, 4, 8>(a, b, st, what);
+    case 24: return launch_phase_rs<MODE, 2, 4>(a, b, st, what);
+    case 28: return launch_phase_rs<MODE, 2, 8>(a, b, st, what);
+    case 14: return launch_phase_rs<MODE, 1, 4>(a, b, st, what);
+    case 216: return launch_phase_rs<MODE, 2, 16>(a, b, st, what);
+    default: return launch_phase_rs<MODE, 1, 8>(a, b, st, what);
+    }
 }
 
 struct StreamBuf {  // stream-ordered scratch (hipMallocAsync / hipFreeAsync)
@@ -557,7 +592,7 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
     PhaseArgs a{};
     a.multiL = multiL; a.multiR = multiR;
     // pass A of the first level
-    a.n_own = n; a.n_cand = m; a.tiles = pcc::ceil_div(n, 64 * kPhR);
+    a.n_own = n; a.n_cand = m;
     a.own_xyz = xyz1; a.cand_xyz = xyz2;
     a.w0 = nullptr; a.w0c = multiR; a.c0 = lc.c[0]; a.first = 1;
     a.ratio_out = lv; a.ratio_stride = kLevels * nm;
@@ -567,7 +602,7 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         float *ratioL = lv + (size_t)i * nm, *ratioR = ratioL + n;
         PhaseArgs pb{};
         pb.multiL = multiL; pb.multiR = multiR; pb.first = (i == 0);
-        pb.n_own = m; pb.n_cand = n; pb.tiles = pcc::ceil_div(m, 64 * kPhR);
+        pb.n_own = m; pb.n_cand = n;
         pb.own_xyz = xyz2; pb.cand_xyz = xyz1;
         pb.w0 = ratioL; pb.w0_stride = kLevels * nm; pb.c0 = lc.c[i];
         pb.remain = temp + n; pb.remain_stride = 2 * nm;
@@ -576,7 +611,7 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         if (rc) return rc;
         PhaseArgs pc{};
         pc.multiL = multiL; pc.multiR = multiR; pc.first = (i == 0);
-        pc.n_own = n; pc.n_cand = m; pc.tiles = pcc::ceil_div(n, 64 * kPhR);
+        pc.n_own = n; pc.n_cand = m;
         pc.own_xyz = xyz1; pc.cand_xyz = xyz2;
         pc.w0 = ratioR; pc.w0_stride = kLevels * nm; pc.c0 = lc.c[i];
         pc.w1 = temp + n; pc.w1_stride = 2 * nm;

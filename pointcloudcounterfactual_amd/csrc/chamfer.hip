@@ -14,9 +14,9 @@
 //     the 9 of compare+2 selects, on a path whose roofline is the f32 VALU rate.
 //   * tie rule and numerics are the oracle's: lowest index wins, d2 = fmaf(dz,dz,fmaf(dx,dx,dy*dy))
 //     on differences, so indices and distances are bit-exact against oracle/structural_oracle.c.
-//   * backward: one workgroup per sample accumulates both gradients in LDS (ds_add_f32) and writes
-//     them out once, coalesced -- no memset, no global atomics (large clouds fall back to a
-//     zero-fill + global-atomic kernel).
+//   * backward: workgroups own destination ranges of both gradients in LDS, write the direct term with
+//     plain stores and fold in the scattered terms with ds_add_f32, then store once, coalesced --
+//     no memset, no global atomics.
 #include "pcc_common.hpp"
 
 namespace {
@@ -179,71 +179,68 @@ __global__ __launch_bounds__(64 * S) void nn_fwd_kernel(int b, int n, const floa
 // ---- backward -------------------------------------------------------------------------------------
 // grad1[j] = 2 g1[j] (p1_j - p2[idx1[j]]) - sum_{k: idx2[k]=j} 2 g2[k] (p2_k - p1_j)   (and symmetric),
 // i.e. exactly the four atomicAdd groups of nndistance.cu:140-145 applied in both directions.
-// One workgroup per sample; both gradient arrays live in LDS while they are accumulated.
-__global__ __launch_bounds__(1024) void nn_bwd_lds_kernel(int n, const float *__restrict__ xyz1, int m,
-                                                           const float *__restrict__ xyz2,
-                                                           const float *__restrict__ gd1,
-                                                           const int *__restrict__ idx1,
-                                                           const float *__restrict__ gd2,
-                                                           const int *__restrict__ idx2,
-                                                           float *__restrict__ grad1, float *__restrict__ grad2) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];  // acc1[n*3] | acc2[m*3]
-    float *acc1 = acc;
-    float *acc2 = acc + (size_t)n * 3;
-    const int smp = blockIdx.x;
-    const int tid = threadIdx.x, T = blockDim.x;
+// Each sample is cut into P destination ranges; a workgroup OWNS one range of grad1 and one of grad2,
+// keeps them in LDS, writes the direct term with plain stores, then scans all nearest-neighbour
+// indices of its sample and accumulates only the scattered terms that land in its range
+// (ds_add_f32).  Outputs are complete and written once, coalesced: no memset, no global atomics, no
+// workspace, and the LDS-atomic load is spread over b*P workgroups.
+__global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *__restrict__ xyz1, int m,
+                                                            const float *__restrict__ xyz2,
+                                                            const float *__restrict__ gd1,
+                                                            const int *__restrict__ idx1,
+                                                            const float *__restrict__ gd2,
+                                                            const int *__restrict__ idx2,
+                                                            float *__restrict__ grad1, float *__restrict__ grad2,
+                                                            int P) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];
+    const int smp = blockIdx.y, p = blockIdx.x;
+    const int tid = threadIdx.x, T = 256;
+    const int j0 = (int)((long long)n * p / P), j1 = (int)((long long)n * (p + 1) / P);
+    const int k0 = (int)((long long)m * p / P), k1 = (int)((long long)m * (p + 1) / P);
+    float *acc1 = acc;                   // [(j1-j0)*3]
+    float *acc2 = acc + (j1 - j0) * 3;   // [(k1-k0)*3]
     const float *p1 = xyz1 + (size_t)smp * n * 3;
     const float *p2 = xyz2 + (size_t)smp * m * 3;
-    for (int i = tid; i < (n + m) * 3; i += T) acc[i] = 0.f;
-    __syncthreads();
-    for (int j = tid; j < n; j += T) {
-        const int j2 = idx1[(size_t)smp * n + j];
-        const float g = gd1[(size_t)smp * n + j] * 2;
+    const int *i1 = idx1 + (size_t)smp * n;
+    const int *i2 = idx2 + (size_t)smp * m;
+    const float *g1 = gd1 + (size_t)smp * n;
+    const float *g2 = gd2 + (size_t)smp * m;
+    // direct terms (one owner per destination -> plain LDS stores)
+    for (int j = j0 + tid; j < j1; j += T) {
+        const int j2 = i1[j];
+        const float g = g1[j] * 2;
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float t = g * (p1[j * 3 + c] - p2[j2 * 3 + c]);
-            atomicAdd(&acc1[j * 3 + c], t);
-            atomicAdd(&acc2[j2 * 3 + c], -t);
-        }
+        for (int c = 0; c < 3; c++) acc1[(j - j0) * 3 + c] = g * (p1[j * 3 + c] - p2[j2 * 3 + c]);
     }
+    for (int k = k0 + tid; k < k1; k += T) {
+        const int k2 = i2[k];
+        const float g = g2[k] * 2;
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc2[(k - k0) * 3 + c] = g * (p2[k * 3 + c] - p1[k2 * 3 + c]);
+    }
+    __syncthreads();
+    // scattered terms landing in this workgroup's ranges
     for (int k = tid; k < m; k += T) {
-        const int k2 = idx2[(size_t)smp * m + k];
-        const float g = gd2[(size_t)smp * m + k] * 2;
+        const int j = i2[k];
+        if (j >= j0 && j < j1) {
+            const float g = g2[k] * 2;
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float t = g * (p2[k * 3 + c] - p1[k2 * 3 + c]);
-            atomicAdd(&acc2[k * 3 + c], t);
-            atomicAdd(&acc1[k2 * 3 + c], -t);
+            for (int c = 0; c < 3; c++) atomicAdd(&acc1[(j - j0) * 3 + c], -(g * (p2[k * 3 + c] - p1[j * 3 + c])));
+        }
+    }
+    for (int j = tid; j < n; j += T) {
+        const int k = i1[j];
+        if (k >= k0 && k < k1) {
+            const float g = g1[j] * 2;
+#pragma unroll
+            for (int c = 0; c < 3; c++) atomicAdd(&acc2[(k - k0) * 3 + c], -(g * (p1[j * 3 + c] - p2[k * 3 + c])));
         }
     }
     __syncthreads();
-    float *o1 = grad1 + (size_t)smp * n * 3;
-    float *o2 = grad2 + (size_t)smp * m * 3;
-    for (int i = tid; i < n * 3; i += T) o1[i] = acc1[i];
-    for (int i = tid; i < m * 3; i += T) o2[i] = acc2[i];
-}
-
-// Fallback for clouds whose two gradient arrays do not fit LDS: zero-fill on the stream, then
-// global float atomics (same arithmetic).
-__global__ __launch_bounds__(256) void nn_bwd_global_kernel(int b, int n, const float *__restrict__ xyz1, int m,
-                                                             const float *__restrict__ xyz2,
-                                                             const float *__restrict__ gd1,
-                                                             const int *__restrict__ idx1,
-                                                             float *__restrict__ grad1, float *__restrict__ grad2) {
-    const size_t total = (size_t)b * n;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const size_t smp = t / n;
-        const int j2 = idx1[t];
-        const float g = gd1[t] * 2;
-        const float *p1 = xyz1 + t * 3;
-        const float *p2 = xyz2 + (smp * m + j2) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float v = g * (p1[c] - p2[c]);
-            atomicAdd(&grad1[t * 3 + c], v);
-            atomicAdd(&grad2[(smp * m + j2) * 3 + c], -v);
-        }
-    }
+    float *o1 = grad1 + ((size_t)smp * n + j0) * 3;
+    float *o2 = grad2 + ((size_t)smp * m + k0) * 3;
+    for (int i = tid; i < (j1 - j0) * 3; i += T) o1[i] = acc1[i];
+    for (int i = tid; i < (k1 - k0) * 3; i += T) o2[i] = acc2[i];
 }
 
 template <int R, int S>
@@ -304,29 +301,15 @@ int pcc_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2
     if (!xyz1 || !xyz2 || !grad_dist1 || !idx1 || !grad_dist2 || !idx2 || !grad_xyz1 || !grad_xyz2)
         return pcc::invalid("nndistancegrad: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t lds = ((size_t)n + m) * 3 * sizeof(float);
-    if (lds <= 160 * 1024) {
-        static bool attr_done = [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void *>(nn_bwd_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-        }();
-        (void)attr_done;
-        hipLaunchKernelGGL(nn_bwd_lds_kernel, dim3(b), dim3(1024), lds, st, n, xyz1, m, xyz2, grad_dist1, idx1,
-                           grad_dist2, idx2, grad_xyz1, grad_xyz2);
-        return pcc::check_launch("nndistancegrad");
-    }
-    hipError_t e = hipMemsetAsync(grad_xyz1, 0, (size_t)b * n * 3 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(grad_xyz2, 0, (size_t)b * m * 3 * sizeof(float), st);
-    if (e != hipSuccess) {
-        pcc::set_error((int)e, "nndistancegrad: hipMemsetAsync failed");
-        return (int)e;
-    }
-    const int grid1 = (int)std::min<size_t>(((size_t)b * n + 255) / 256, 8192);
-    const int grid2 = (int)std::min<size_t>(((size_t)b * m + 255) / 256, 8192);
-    hipLaunchKernelGGL(nn_bwd_global_kernel, dim3(grid1), dim3(256), 0, st, b, n, xyz1, m, xyz2, grad_dist1, idx1,
-                       grad_xyz1, grad_xyz2);
-    hipLaunchKernelGGL(nn_bwd_global_kernel, dim3(grid2), dim3(256), 0, st, b, m, xyz2, n, xyz1, grad_dist2, idx2,
-                       grad_xyz2, grad_xyz1);
+    // P destination ranges per sample: ~512 workgroups on the chip, each range pair <= 48 KiB of LDS.
+    long long P = std::max<long long>(1, pcc::ceil_div(512, b));
+    P = std::min<long long>(P, std::max(1, std::min(n, m) / 64));
+    const long long lds_min = ((long long)n + m) * 12 / (48 * 1024) + 1;
+    P = std::max(P, lds_min);
+    if (P > 65535) return pcc::invalid("nndistancegrad: clouds too large");
+    const size_t lds = ((size_t)pcc::ceil_div(n, (int)P) + pcc::ceil_div(m, (int)P) + 2) * 3 * sizeof(float);
+    hipLaunchKernelGGL(nn_bwd_range_kernel, dim3((unsigned)P, (unsigned)b), dim3(256), lds, st, n, xyz1, m, xyz2,
+                       grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, (int)P);
     return pcc::check_launch("nndistancegrad");
 }
 

@@ -12,7 +12,9 @@ def ref_cloud(rng: np.random.Generator, b: int, n: int) -> np.ndarray:
     r = rng.uniform(0.3, 1.0, (b, n, 1)) ** (1.0 / 3.0)
     p = v * r
     p -= p.mean(axis=1, keepdims=True)
-    p /= np.linalg.norm(p, axis=2).max(axis=1)[:, None, None]
+    p /= np.maximum(np.linalg.norm(p, axis=2).max(axis=1), 1e-12)[:, None, None]
+    if n == 1:
+        p = v * r  # a single point cannot be centred; keep it off the origin
     return p.astype(np.float32)
 
 
