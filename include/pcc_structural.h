@@ -40,6 +40,16 @@ const char *pcc_last_error(void);
 /* Status of the last reference-named (void) launcher call on this thread; reset to 0 by each call. */
 int pcc_last_status(void);
 
+/* ---- per-kernel timing (measurement aid, off by default) ----------------------------------------
+ * When enabled, every kernel launch of this library is bracketed by two hipEvents recorded on the
+ * launch stream.  pcc_profile_read synchronises on the recorded events and returns the average
+ * duration (microseconds) and the number of launches whose kernel name starts with `kernel_prefix`
+ * since the last pcc_profile_enable(1) / pcc_profile_reset().  Returns 0, or PCC_EINVAL if nothing
+ * matched.  Not thread-safe against concurrent launches; meant for bench.py. */
+void pcc_profile_enable(int on);
+void pcc_profile_reset(void);
+int pcc_profile_read(const char *kernel_prefix, double *avg_us, int *launches);
+
 /* ---- Chamfer nearest neighbour ---------------------------------------------------------------
  * Replaces `nndistance` (reference nndistance.cu:125-128; declared structural_loss.cpp:13).
  *   xyz[b,n,3], xyz2[b,m,3] -> result[b,n] = min_k |xyz_j - xyz2_k|^2, result_i[b,n] = argmin

@@ -21,6 +21,9 @@ ABI: dict[str, tuple[object, list[object]]] = {
     'pcc_version': (ctypes.c_char_p, []),
     'pcc_last_error': (ctypes.c_char_p, []),
     'pcc_last_status': (_int, []),
+    'pcc_profile_enable': (None, [_int]),
+    'pcc_profile_reset': (None, []),
+    'pcc_profile_read': (_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     'nndistance': (None, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcc_nndistance': (_int, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'nndistancegrad': (None, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -517,7 +517,11 @@ int launch_phase_rs(PhaseArgs a, int b, hipStream_t st, const char *what) {
     a.tiles = pcc::ceil_div(a.n_own, 64 * R);
     const long long grid = (long long)b * a.tiles;
     if (grid > 0x7fffffffLL) return pcc::invalid("approxmatch: grid too large");
-    hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH>), dim3((unsigned)grid), dim3(64 * S), 0, st, a);
+    {
+        pcc::ProfScope prof(MODE == PH_CA ? "am_phase_kernel<CA>" : MODE == PH_B ? "am_phase_kernel<B>"
+                            : MODE == PH_A ? "am_phase_kernel<A>" : "am_phase_kernel<C>", st);
+        hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH>), dim3((unsigned)grid), dim3(64 * S), 0, st, a);
+    }
     return pcc::check_launch(what);
 }
 
@@ -629,15 +633,21 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
     const dim3 grid(pcc::ceil_div(n, kMatKT), pcc::ceil_div(m, kMatLT), b);
     const bool vec = (n % 4 == 0) && aligned16(match);
     if (cost_out) {
-        if (vec) hipLaunchKernelGGL((am_materialise_kernel<true, true>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, cpart);
-        else hipLaunchKernelGGL((am_materialise_kernel<true, false>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, cpart);
+        {
+            pcc::ProfScope prof("am_materialise_kernel<cost>", st);
+            if (vec) hipLaunchKernelGGL((am_materialise_kernel<true, true>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, cpart);
+            else hipLaunchKernelGGL((am_materialise_kernel<true, false>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, cpart);
+        }
         rc = pcc::check_launch("approxmatch(materialise+cost)");
         if (rc) return rc;
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(b), dim3(256), 0, st, (int)cost_parts(n, m), cpart, cost_out);
         return pcc::check_launch("approxmatch(cost reduce)");
     }
-    if (vec) hipLaunchKernelGGL((am_materialise_kernel<false, true>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, nullptr);
-    else hipLaunchKernelGGL((am_materialise_kernel<false, false>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, nullptr);
+    {
+        pcc::ProfScope prof("am_materialise_kernel", st);
+        if (vec) hipLaunchKernelGGL((am_materialise_kernel<false, true>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, nullptr);
+        else hipLaunchKernelGGL((am_materialise_kernel<false, false>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, nullptr);
+    }
     return pcc::check_launch("approxmatch(materialise)");
 }
 
@@ -719,8 +729,11 @@ int pcc_matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, con
     if (int rc = ws.alloc((size_t)b * tiles * sizeof(float))) return rc;
     float *part = static_cast<float *>(ws.p);
     const bool vec = (n % 4 == 0) && aligned16(match);
-    if (vec) hipLaunchKernelGGL((am_row_kernel<0, true, 2048>), dim3(tiles, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, part);
-    else hipLaunchKernelGGL((am_row_kernel<0, false, 2048>), dim3(tiles, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, part);
+    {
+        pcc::ProfScope prof("am_row_kernel<cost>", st);
+        if (vec) hipLaunchKernelGGL((am_row_kernel<0, true, 2048>), dim3(tiles, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, part);
+        else hipLaunchKernelGGL((am_row_kernel<0, false, 2048>), dim3(tiles, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, part);
+    }
     if (int rc = pcc::check_launch("matchcost")) return rc;
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(b), dim3(256), 0, st, tiles, part, out);
     return pcc::check_launch("matchcost(reduce)");
@@ -747,8 +760,11 @@ int pcc_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2,
     const bool vec = (n % 4 == 0) && aligned16(match);
     // grad2: row kernel
     const int tiles = pcc::ceil_div(m, kRowRT);
-    if (vec) hipLaunchKernelGGL((am_row_kernel<1, true, 2048>), dim3(tiles, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
-    else hipLaunchKernelGGL((am_row_kernel<1, false, 2048>), dim3(tiles, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
+    {
+        pcc::ProfScope prof("am_row_kernel<grad2>", st);
+        if (vec) hipLaunchKernelGGL((am_row_kernel<1, true, 2048>), dim3(tiles, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
+        else hipLaunchKernelGGL((am_row_kernel<1, false, 2048>), dim3(tiles, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
+    }
     if (int rc = pcc::check_launch("matchcostgrad(grad2)")) return rc;
     // grad1: column kernel with RS row splits, then ordered sum of the partials
     const int ctiles = pcc::ceil_div(n, 256);
@@ -757,8 +773,11 @@ int pcc_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2,
     StreamBuf ws(st);
     if (int rc = ws.alloc((size_t)b * rs * n * 3 * sizeof(float))) return rc;
     float *part = static_cast<float *>(ws.p);
-    if (vec) hipLaunchKernelGGL((am_col_kernel<true>), dim3(ctiles, rs, b), dim3(256), 0, st, n, m, rs, xyz1, xyz2, match, part);
-    else hipLaunchKernelGGL((am_col_kernel<false>), dim3(ctiles, rs, b), dim3(256), 0, st, n, m, rs, xyz1, xyz2, match, part);
+    {
+        pcc::ProfScope prof("am_col_kernel<grad1>", st);
+        if (vec) hipLaunchKernelGGL((am_col_kernel<true>), dim3(ctiles, rs, b), dim3(256), 0, st, n, m, rs, xyz1, xyz2, match, part);
+        else hipLaunchKernelGGL((am_col_kernel<false>), dim3(ctiles, rs, b), dim3(256), 0, st, n, m, rs, xyz1, xyz2, match, part);
+    }
     if (int rc = pcc::check_launch("matchcostgrad(grad1)")) return rc;
     const size_t per = (size_t)n * 3;
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((per + 255) / 256), b), dim3(256), 0, st, rs, per, part, grad1);

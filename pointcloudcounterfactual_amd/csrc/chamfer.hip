@@ -250,8 +250,11 @@ int launch_fwd(int b, int n, const float *xyz, int m, const float *xyz2, float *
     const int tiles_n = pcc::ceil_div(n, 64 * R), tiles_m = pcc::ceil_div(m, 64 * R);
     const long long grid = (long long)b * (tiles_n + tiles_m);
     if (grid > 0x7fffffffLL) return pcc::invalid("nndistance: grid too large");
-    hipLaunchKernelGGL((nn_fwd_kernel<R, S, CH>), dim3((unsigned)grid), dim3(64 * S), 0, st, b, n, xyz, m, xyz2, res1,
-                       idx1, res2, idx2, tiles_n, tiles_m);
+    {
+        pcc::ProfScope prof("nn_fwd_kernel", st);
+        hipLaunchKernelGGL((nn_fwd_kernel<R, S, CH>), dim3((unsigned)grid), dim3(64 * S), 0, st, b, n, xyz, m, xyz2,
+                           res1, idx1, res2, idx2, tiles_n, tiles_m);
+    }
     return pcc::check_launch("nndistance");
 }
 
@@ -308,8 +311,11 @@ int pcc_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2
     P = std::max(P, lds_min);
     if (P > 65535) return pcc::invalid("nndistancegrad: clouds too large");
     const size_t lds = ((size_t)pcc::ceil_div(n, (int)P) + pcc::ceil_div(m, (int)P) + 2) * 3 * sizeof(float);
-    hipLaunchKernelGGL(nn_bwd_range_kernel, dim3((unsigned)P, (unsigned)b), dim3(256), lds, st, n, xyz1, m, xyz2,
-                       grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, (int)P);
+    {
+        pcc::ProfScope prof("nn_bwd_range_kernel", st);
+        hipLaunchKernelGGL(nn_bwd_range_kernel, dim3((unsigned)P, (unsigned)b), dim3(256), lds, st, n, xyz1, m, xyz2,
+                           grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, (int)P);
+    }
     return pcc::check_launch("nndistancegrad");
 }
 

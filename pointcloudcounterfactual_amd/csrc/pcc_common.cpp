@@ -1,6 +1,10 @@
 // Per-thread error record and library info for libpcc_structural.so.
 #include "pcc_common.hpp"
 
+#include <mutex>
+#include <string>
+#include <vector>
+
 namespace {
 thread_local int t_status = 0;
 thread_local char t_msg[320] = "";
@@ -16,9 +20,74 @@ void clear_error() {
     t_status = 0;
     t_msg[0] = '\0';
 }
+
+namespace {
+struct ProfRec {
+    const char *name;
+    hipEvent_t a, b;
+};
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+void prof_clear() {
+    for (auto &r : g_prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+}
+}  // namespace
+
+bool profiling() { return g_prof_on; }
+ProfScope::ProfScope(const char *kernel, hipStream_t s) : st(s), name(kernel) {
+    if (!g_prof_on) return;
+    if (hipEventCreate(&start) != hipSuccess) {
+        start = nullptr;
+        return;
+    }
+    (void)hipEventRecord(start, st);
+}
+ProfScope::~ProfScope() {
+    if (!start) return;
+    hipEvent_t stop;
+    if (hipEventCreate(&stop) != hipSuccess) {
+        (void)hipEventDestroy(start);
+        return;
+    }
+    (void)hipEventRecord(stop, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back({name, start, stop});
+}
 }  // namespace pcc
 
 extern "C" {
+void pcc_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(pcc::g_prof_mu);
+    pcc::g_prof_on = on != 0;
+    if (on) pcc::prof_clear();
+}
+void pcc_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(pcc::g_prof_mu);
+    pcc::prof_clear();
+}
+int pcc_profile_read(const char *kernel_prefix, double *avg_us, int *launches) {
+    std::lock_guard<std::mutex> lk(pcc::g_prof_mu);
+    const std::string pre = kernel_prefix ? kernel_prefix : "";
+    double total_ms = 0;
+    int n = 0;
+    for (auto &r : pcc::g_prof) {
+        if (std::string(r.name).compare(0, pre.size(), pre) != 0) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        total_ms += ms;
+        n++;
+    }
+    if (avg_us) *avg_us = n ? total_ms * 1e3 / n : 0.0;
+    if (launches) *launches = n;
+    return n ? PCC_OK : PCC_EINVAL;
+}
+
 const char *pcc_version(void) { return "pcc_structural 0.1 (gfx950)"; }
 const char *pcc_last_error(void) { return t_msg; }
 int pcc_last_status(void) { return t_status; }

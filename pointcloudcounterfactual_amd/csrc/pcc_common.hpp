@@ -38,6 +38,16 @@ __device__ __forceinline__ float sq3(float x, float y, float z) {
     return __builtin_fmaf(z, z, __builtin_fmaf(x, x, y * y));
 }
 
+// Optional hipEvent bracket around one kernel launch (pcc_profile_* in the C ABI).
+bool profiling();
+struct ProfScope {
+    hipEvent_t start = nullptr;
+    hipStream_t st;
+    const char *name;
+    ProfScope(const char *kernel, hipStream_t s);
+    ~ProfScope();
+};
+
 __host__ __device__ constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace pcc

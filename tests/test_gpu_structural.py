@@ -216,3 +216,26 @@ def test_full_size_properties(cuda, kind):
     # cost is bounded below by the nearest-neighbour transport and above by mass * diameter
     lower = 0.5 * (d1.sqrt().sum(1) + d2.sqrt().sum(1)) * 0.98
     assert (cost >= lower * 0.99).all() and (cost <= 2048 * 2.0).all()
+
+
+@pytest.mark.parametrize('tag', list('abcde'))
+def test_against_committed_golden_fixture(cuda, tag):
+    """HIP path vs tests/golden/oracle_structural.npz (no oracle build needed for this one)."""
+    import os
+
+    from pointcloudcounterfactual_amd import backend
+
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'oracle_structural.npz'), allow_pickle=False)
+    s1, s2 = _dev(z[f'{tag}_set1'], cuda), _dev(z[f'{tag}_set2'], cuda)
+    d1, i1, d2, i2 = backend.NNDistance(s1, s2)
+    assert np.array_equal(d1.cpu().numpy(), z[f'{tag}_dist1']) and np.array_equal(i1.cpu().numpy(), z[f'{tag}_idx1'])
+    assert np.array_equal(d2.cpu().numpy(), z[f'{tag}_dist2']) and np.array_equal(i2.cpu().numpy(), z[f'{tag}_idx2'])
+    g1, g2 = backend.NNDistanceGrad(s1, s2, i1, i2, _dev(z[f'{tag}_gdist1'], cuda), _dev(z[f'{tag}_gdist2'], cuda))
+    np.testing.assert_allclose(g1.cpu().numpy(), z[f'{tag}_nngrad1'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g2.cpu().numpy(), z[f'{tag}_nngrad2'], rtol=1e-5, atol=1e-6)
+    match, temp, cost = backend.ApproxMatchCost(s1, s2)
+    np.testing.assert_allclose(cost.cpu().numpy(), z[f'{tag}_cost'], rtol=1e-5)
+    gm1, gm2 = backend.MatchCostGrad(s1, s2, _dev(z[f'{tag}_match'], cuda))
+    scale = max(np.abs(z[f'{tag}_mgrad1']).max(), np.abs(z[f'{tag}_mgrad2']).max())
+    np.testing.assert_allclose(gm1.cpu().numpy(), z[f'{tag}_mgrad1'], rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(gm2.cpu().numpy(), z[f'{tag}_mgrad2'], rtol=1e-5, atol=1e-5 * scale)

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root).
+#   tools/profile_bench.sh <tag>   -> gpurun_out/<tag>_{stats,pmc_fetch,pmc_write,pmc_sq}/...
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $R/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/${TAG}_pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $R/bench.py $ARGS > $OUT/${TAG}_pmc_write.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/${TAG}_pmc_sq -- python3 $R/bench.py $ARGS > $OUT/${TAG}_pmc_sq.log 2>&1 || exit 1
+echo profiled

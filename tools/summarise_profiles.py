@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 outputs under gpurun_out/<tag>_* into small tracked summaries under profiles/.
+
+  profiles/<tag>_kernel_stats.csv   per-kernel calls / avg / total from --kernel-trace --stats
+  profiles/<tag>_pmc.csv            per-kernel averages of the PMC passes (FETCH_SIZE, WRITE_SIZE, SQ_*)
+  profiles/pmc_summary.json         HBM bytes per launch for the dominant kernels, corrected as
+                                    MI355X_MICROARCH.md prescribes (FETCH_SIZE is in KiB and under-reports
+                                    wide coalesced reads by 2x on gfx950; WRITE_SIZE is exact)
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+out_tag = sys.argv[2] if len(sys.argv) > 2 else tag
+G = os.path.join(ROOT, 'gpurun_out')
+P = os.path.join(ROOT, 'profiles')
+os.makedirs(P, exist_ok=True)
+
+
+def short(name: str) -> str:
+    m = re.search(r'(am_\w+|nn_\w+|reduce_\w+|knn_\w+|graph_\w+|auction_\w+|emd_\w+)(<[^>(]*>)?', name)
+    if m:
+        return m.group(0)
+    return re.sub(r'\(.*', '', name)[:80]
+
+
+def one(pattern: str) -> str | None:
+    files = glob.glob(os.path.join(G, pattern))
+    return files[0] if files else None
+
+
+stats = one(f'{tag}_stats/*/*kernel_stats.csv')
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(P, f'{out_tag}_kernel_stats.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'calls', 'avg_us', 'min_us', 'max_us', 'total_ms', 'percent'])
+        for r in rows:
+            w.writerow([short(r['Name']), r['Calls'], f"{float(r['AverageNs']) / 1e3:.2f}", f"{float(r['MinNs']) / 1e3:.2f}",
+                        f"{float(r['MaxNs']) / 1e3:.2f}", f"{float(r['TotalDurationNs']) / 1e6:.3f}", r['Percentage']])
+    print('wrote', f'profiles/{out_tag}_kernel_stats.csv')
+
+pmc: dict[str, dict[str, list[float]]] = defaultdict(lambda: defaultdict(list))
+for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
+    f = one(f'{tag}_{sub}/*/*counter_collection.csv')
+    if not f:
+        continue
+    for r in csv.DictReader(open(f)):
+        pmc[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+if pmc:
+    counters = sorted({c for k in pmc.values() for c in k})
+    with open(os.path.join(P, f'{out_tag}_pmc.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'dispatches'] + [f'avg_{c}' for c in counters])
+        for k, d in sorted(pmc.items()):
+            n = max(len(v) for v in d.values())
+            w.writerow([k, n] + [f'{sum(d[c]) / len(d[c]):.1f}' if d.get(c) else '' for c in counters])
+    print('wrote', f'profiles/{out_tag}_pmc.csv')
+    summary = {}
+    for k, d in pmc.items():
+        if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+            fetch_kib = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE'])
+            write_kib = sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])
+            key = re.sub(r'<.*', '', k)
+            summary.setdefault(key, {'fetch_kib_raw': 0.0, 'write_kib': 0.0, 'variants': 0})
+            summary[key]['fetch_kib_raw'] += fetch_kib
+            summary[key]['write_kib'] += write_kib
+            summary[key]['variants'] += 1
+    for key, v in summary.items():
+        n = v.pop('variants')
+        v['fetch_kib_raw'] /= n
+        v['write_kib'] /= n
+        # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2 (upper bound for
+        # narrow accesses); WRITE_SIZE is exact.  Units are KiB.
+        v['hbm_bytes_per_launch'] = (2.0 * v['fetch_kib_raw'] + v['write_kib']) * 1024.0
+        v['source'] = f'profiles/{out_tag}_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+    json.dump(summary, open(os.path.join(P, 'pmc_summary.json'), 'w'), indent=1)
+    print('wrote profiles/pmc_summary.json')
