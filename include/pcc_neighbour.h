@@ -1,0 +1,66 @@
+/*
+ * pcc_neighbour.h -- C ABI of the kNN-graph / neighbour-gather / max-pool primitives in
+ * libpcc_structural.so (MI355X / gfx950).
+ *
+ * The reference has no native boundary for these: they are Python functions in
+ * src/utils/neighbour_ops.py that call PyKeOps (GPU) or torch (CPU).  Each entry cites the function it
+ * replaces.  Tensors are contiguous row-major device arrays in the reference's layouts:
+ *   x[b, c, n] float32 (channels-major), indices[b, n, k] int64.
+ * All entries enqueue on `stream` (hipStream_t as void*), never synchronise, and return 0 or an error code
+ * (message via pcc_last_error(), include/pcc_structural.h).
+ */
+#ifndef PCC_NEIGHBOUR_H
+#define PCC_NEIGHBOUR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "pcc_structural.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+/* knn / pykeops_knn (neighbour_ops.py:63-82): for every point the k nearest points of the same cloud in
+ * feature space, ascending distance (the point itself first), ties by ascending index.
+ *   c <= 3 : exact difference form sum_c (x_j - x_i)^2 on the f32 VALU (the GPU reference's formula, :35-40)
+ *   c >= 4 : expanded form |x_i|^2 + |x_j|^2 - 2 x_i.x_j with the inner product on the f32 MFMA pipe
+ *            (the reference CPU path's formula, self_square_distance :53-60)
+ * Requires 1 <= k <= min(n, 32). */
+int pcc_knn(int b, int c, int n, int k, const float *x, int64_t *indices, pcc_stream_t stream);
+
+/* get_neighbours (neighbour_ops.py:85-94): out[b,c,n,j] = x[b,c,indices[b,n,j]]. */
+int pcc_gather_neighbours(int b, int c, int n, int k, const float *x, const int64_t *indices, float *out,
+                          pcc_stream_t stream);
+/* backward of the gather: grad_x[b,c,t] = sum over (n,j) with indices[b,n,j]==t of grad_out[b,c,n,j].
+ * grad_x is overwritten. */
+int pcc_gather_neighbours_bwd(int b, int c, int n, int k, const int64_t *indices, const float *grad_out,
+                              float *grad_x, pcc_stream_t stream);
+
+/* get_graph_features (neighbour_ops.py:113-119): out[b, 0:c, n, j] = x[b,:,indices[b,n,j]] - x[b,:,n],
+ * out[b, c:2c, n, j] = x[b,:,n]. */
+int pcc_graph_features(int b, int c, int n, int k, const float *x, const int64_t *indices, float *out,
+                       pcc_stream_t stream);
+/* backward: grad_x[b,c,t] = sum_{(n,j): idx=t} g[b,c,n,j] + sum_j (g[b,c+C,t,j] - g[b,c,t,j]). */
+int pcc_graph_features_bwd(int b, int c, int n, int k, const int64_t *indices, const float *grad_out,
+                           float *grad_x, pcc_stream_t stream);
+
+/* graph_max_pooling (neighbour_ops.py:106-110): out[b,c,n] = max_j x[b,c,indices[b,n,j]];
+ * argmax[b,c,n] (int32, the winning j, first on ties as torch.max) is written when non-null. */
+int pcc_graph_max_pool(int b, int c, int n, int k, const float *x, const int64_t *indices, float *out,
+                       int32_t *argmax, pcc_stream_t stream);
+int pcc_graph_max_pool_bwd(int b, int c, int n, int k, const int64_t *indices, const int32_t *argmax,
+                           const float *grad_out, float *grad_x, pcc_stream_t stream);
+
+/* Encoder / classifier global pooling (src/module/encoders.py:58,90; classifier.py:63-64):
+ * out_max[b,c] = max_n x[b,c,n] with argmax[b,c] (int32, first maximum), out_mean[b,c] = mean_n (either
+ * output pointer may be null). */
+int pcc_global_pool(int b, int c, int n, const float *x, float *out_max, int32_t *argmax, float *out_mean,
+                    pcc_stream_t stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCC_NEIGHBOUR_H */

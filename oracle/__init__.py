@@ -30,7 +30,7 @@ def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (``make -C oracle``)."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ('structural_oracle.c', 'auction_oracle.c', 'Makefile')
+        for f in ('structural_oracle.c', 'auction_oracle.c', 'neighbour_oracle.c', 'Makefile')
     ):
         subprocess.check_call(['make', '-C', _HERE, '-s'] + (['-B'] if force else []))
     return _LIB_PATH
@@ -170,3 +170,26 @@ def matchcostgrad_f64(set1, set2, match):
     g2 = np.zeros((b, m, 3), np.float64)
     lib().oracle_matchcostgrad_f64(b, n, m, _p(set1), _p(set2), _p(match, _f64p), _p(g1, _f64p), _p(g2, _f64p))
     return g1, g2
+
+
+# ---- kNN (neighbour_oracle.c) -----------------------------------------------------------------------------------
+_i64p = ctypes.POINTER(ctypes.c_int64)
+
+
+def knn_diff(x, k: int):
+    """Difference-form kNN of x[B,C,N] -> idx[B,N,k] int64 (pykeops_knn formula, neighbour_ops.py:77-82)."""
+    x = _f(x)
+    b, c, n = x.shape
+    idx = np.zeros((b, n, k), np.int64)
+    lib().oracle_knn_diff(b, c, n, int(k), _p(x), _p(idx, _i64p))
+    return idx
+
+
+def knn_expanded(x, k: int, return_dist: bool = False):
+    """Expanded-form kNN (torch_knn formula, neighbour_ops.py:53-74) with sequential-fma rounding."""
+    x = _f(x)
+    b, c, n = x.shape
+    idx = np.zeros((b, n, k), np.int64)
+    dist = np.zeros((b, n, n), np.float32) if return_dist else None
+    lib().oracle_knn_expanded(b, c, n, int(k), _p(x), _p(idx, _i64p), _p(dist) if return_dist else None)
+    return (idx, dist) if return_dist else idx

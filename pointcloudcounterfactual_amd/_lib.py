@@ -11,7 +11,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpcc_structural.so')
+LIB_PATH = os.environ.get('PCC_LIB_OVERRIDE') or os.path.join(_HERE, 'lib', 'libpcc_structural.so')  # override: A/B builds only
 
 _vp = ctypes.c_void_p
 _int = ctypes.c_int
@@ -37,6 +37,15 @@ ABI: dict[str, tuple[object, list[object]]] = {
     'pcc_matchcost': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     'matchcostgrad': (None, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcc_matchcostgrad': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    # include/pcc_neighbour.h
+    'pcc_knn': (_int, [_int, _int, _int, _int, _vp, _vp, _vp]),
+    'pcc_gather_neighbours': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    'pcc_gather_neighbours_bwd': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    'pcc_graph_features': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    'pcc_graph_features_bwd': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    'pcc_graph_max_pool': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_graph_max_pool_bwd': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_global_pool': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
 }
 
 

@@ -1,0 +1,327 @@
+// k-nearest-neighbour graph for gfx950 (MI355X), wave64.
+//
+// Replaces knn / pykeops_knn (reference src/utils/neighbour_ops.py:63-82: a PyKeOps argKmin over a lazy
+// (B,N,N) squared-distance tensor) -- PyKeOps has no ROCm backend.  Two kernels:
+//   * knn_small_kernel (c <= 3): exact difference-form distances on the f32 VALU, the formula the GPU
+//     reference evaluates (pykeops_square_distance, :35-40).  A lane owns one query; the candidate cloud sits
+//     in LDS as SoA rows (x is already channels-major, so staging is a straight coalesced copy); S waves
+//     scan disjoint candidate ranges; per-lane buffered top-K (topk.hpp); the S sorted lists are merged
+//     with strict '<' in range order, so equal distances come out in ascending index order.
+//   * knn_mfma_kernel (c >= 4): expanded form |xi|^2 + |xj|^2 - 2 xi.xj with the inner product on
+//     v_mfma_f32_32x32x2_f32 (exact f32 FMA chain per output) -- the formula of the reference's CPU path
+//     (self_square_distance, :53-60) and a genuine dense contraction (C = 64..128 in the DGCNN encoder).
+//     The 32x32 accumulator tile is oriented with the QUERY on the lane (column) and 16 candidates in
+//     the lane's accumulator registers, so the same per-lane top-K consumes distances straight from
+//     registers: the (B,N,N) distance matrix never exists in memory.
+#include "pcc_common.hpp"
+#include "pcc_neighbour.h"
+#include "topk.hpp"
+
+namespace {
+
+constexpr int kCap = 16;     // FIFO slots per lane
+constexpr int kCH = 2048;    // candidates staged per chunk (small-c kernel)
+
+template <int K, int S>
+struct SmallLayout {
+    static constexpr int T = 64 * S;
+    static constexpr int cand_bytes = 3 * kCH * 4;
+    static constexpr int buf_bytes = 2 * kCap * T * 4;
+    static constexpr int merge_bytes = 2 * S * K * 64 * 4;
+    static constexpr int bytes = (cand_bytes + buf_bytes) > merge_bytes ? (cand_bytes + buf_bytes) : merge_bytes;
+};
+
+// Merge S sorted K-lists per lane (LDS layout [s][slot][lane]) and write the first k indices as int64.
+template <int K, int S>
+__device__ __forceinline__ void merge_and_store(const float *md, const int *mi, int lane, int k, int64_t *dst) {
+    int p[S];
+    float h[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        p[s] = 0;
+        h[s] = md[(s * K) * 64 + lane];
+    }
+    for (int o = 0; o < k; o++) {
+        int best = 0;
+        float bv = h[0];
+#pragma unroll
+        for (int s = 1; s < S; s++) {
+            const bool lt = h[s] < bv;  // strict: the earlier candidate range wins ties
+            bv = lt ? h[s] : bv;
+            best = lt ? s : best;
+        }
+        int pos = 0;
+#pragma unroll
+        for (int s = 0; s < S; s++) pos = (best == s) ? p[s] : pos;
+        dst[o] = (int64_t)mi[(best * K + pos) * 64 + lane];
+        const int np = pos + 1;
+        const float nh = np < K ? md[(best * K + np) * 64 + lane] : __builtin_inff();
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const bool sel = best == s;
+            p[s] = sel ? np : p[s];
+            h[s] = sel ? nh : h[s];
+        }
+    }
+}
+
+template <int K, int S>
+__global__ __launch_bounds__(64 * S) void knn_small_kernel(int c, int n, int k, const float *__restrict__ x,
+                                                            int64_t *__restrict__ indices) {
+    using L = SmallLayout<K, S>;
+    constexpr int T = L::T;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[L::bytes];
+    float *lds_c = reinterpret_cast<float *>(smem);
+    float *buf_d = reinterpret_cast<float *>(smem + L::cand_bytes);
+    int *buf_i = reinterpret_cast<int *>(smem + L::cand_bytes + kCap * T * 4);
+    float *mrg_d = reinterpret_cast<float *>(smem);
+    int *mrg_i = reinterpret_cast<int *>(smem + S * K * 64 * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int smp = blockIdx.y;
+    const float *xb = x + (size_t)smp * c * n;
+    int q = blockIdx.x * 64 + lane;
+    const bool q_ok = q < n;
+    q = q_ok ? q : n - 1;
+    const float qx = xb[q];
+    const float qy = c > 1 ? xb[(size_t)n + q] : 0.f;
+    const float qz = c > 2 ? xb[(size_t)2 * n + q] : 0.f;
+
+    pcc::BufferedTopK<K, kCap, T> tk;
+    tk.init(buf_d, buf_i, tid);
+
+    const float4 *X4 = reinterpret_cast<const float4 *>(lds_c);
+    const float4 *Y4 = X4 + kCH / 4;
+    const float4 *Z4 = Y4 + kCH / 4;
+
+    for (int c0 = 0; c0 < n; c0 += kCH) {
+        const int cnt = min(kCH, n - c0);
+        const int ngroups = (cnt + 7) / 8;
+        if (c0) __syncthreads();
+        for (int ch = 0; ch < 3; ch++) {
+            for (int i = tid; i < ngroups * 8; i += T)
+                lds_c[ch * kCH + i] = (i < cnt) ? (ch < c ? xb[(size_t)ch * n + c0 + i] : 0.f) : __builtin_inff();
+        }
+        __syncthreads();
+        const int gs = (ngroups + S - 1) / S;
+        const int g_begin = w * gs;
+        const int g_end = min(g_begin + gs, ngroups);
+        for (int g = g_begin; g < g_end; g++) {
+            const float4 xa = X4[2 * g], xb4 = X4[2 * g + 1];
+            const float4 ya = Y4[2 * g], yb4 = Y4[2 * g + 1];
+            const float4 za = Z4[2 * g], zb4 = Z4[2 * g + 1];
+            const float cx[8] = {xa.x, xa.y, xa.z, xa.w, xb4.x, xb4.y, xb4.z, xb4.w};
+            const float cy[8] = {ya.x, ya.y, ya.z, ya.w, yb4.x, yb4.y, yb4.z, yb4.w};
+            const float cz[8] = {za.x, za.y, za.z, za.w, zb4.x, zb4.y, zb4.z, zb4.w};
+            if (tk.must_flush(8)) tk.flush();
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float dx = cx[j] - qx, dy = cy[j] - qy, dz = cz[j] - qz;
+                // sum over channels in channel order: ((dx^2 + dy^2) + dz^2) as an fma chain
+                const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                tk.offer(d, c0 + g * 8 + j);
+            }
+        }
+    }
+    tk.flush();
+    __syncthreads();  // every wave is done with the candidate / FIFO regions: reuse them for the merge
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        mrg_d[(w * K + s) * 64 + lane] = tk.top.d[s];
+        mrg_i[(w * K + s) * 64 + lane] = tk.top.i[s];
+    }
+    __syncthreads();
+    if (w == 0 && q_ok) merge_and_store<K, S>(mrg_d, mrg_i, lane, k, indices + ((size_t)smp * n + q) * k);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// c >= 4: MFMA kernel.
+// Workgroup = 4 waves, each wave 32 queries (columns of the 32x32 accumulator tile = lane & 31); the two
+// half-waves hold different candidate rows of the tile (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), so each
+// query has two partial top-K lists which are merged at the end.  Candidate tiles [c][32] are staged in
+// LDS once per workgroup and shared by the 4 waves.  B operand (queries) lives in c/2 VGPRs per lane.
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(int c, int n, const float *__restrict__ x, float *__restrict__ sq) {
+    // sq[b][i] = sum_c x[b,c,i]^2 in channel order
+    const int smp = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *xb = x + (size_t)smp * c * n;
+    float s = 0.f;
+    for (int ch = 0; ch < c; ch++) {
+        const float v = xb[(size_t)ch * n + i];
+        s = __builtin_fmaf(v, v, s);
+    }
+    sq[(size_t)smp * n + i] = s;
+}
+
+template <int K, int CP /* padded channels, multiple of 2, <= 128 */>
+__global__ __launch_bounds__(256) void knn_mfma_kernel(int c, int n, int k, const float *__restrict__ x,
+                                                        const float *__restrict__ sq,
+                                                        int64_t *__restrict__ indices) {
+    constexpr int T = 256;
+    constexpr int KS = CP / 2;  // MFMA k-steps (32x32x2)
+    constexpr int tile_bytes = CP * 32 * 4;
+    constexpr int buf_bytes = 2 * kCap * T * 4;
+    constexpr int merge_bytes = 2 * 8 * K * 32 * 4;  // [wave(4)][half(2)][K][32 queries]
+    constexpr int main_bytes = 2 * tile_bytes + 2 * 32 * 4 + buf_bytes;
+    constexpr int bytes = main_bytes > merge_bytes ? main_bytes : merge_bytes;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[bytes];
+    float *tile = reinterpret_cast<float *>(smem);                       // [2][CP][32]
+    float *tsq = reinterpret_cast<float *>(smem + 2 * tile_bytes);      // [2][32]
+    float *buf_d = reinterpret_cast<float *>(smem + 2 * tile_bytes + 2 * 32 * 4);
+    int *buf_i = reinterpret_cast<int *>(smem + 2 * tile_bytes + 2 * 32 * 4 + kCap * T * 4);
+    float *mrg_d = reinterpret_cast<float *>(smem);
+    int *mrg_i = reinterpret_cast<int *>(smem + 8 * K * 32 * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int smp = blockIdx.y;
+    const float *xb = x + (size_t)smp * c * n;
+    const float *sqb = sq + (size_t)smp * n;
+    int q = blockIdx.x * 128 + w * 32 + col;
+    const bool q_ok = q < n;
+    q = q_ok ? q : n - 1;
+    // B operand: query[col][k = 2*ks + half]
+    float bq[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const int ch = 2 * ks + half;
+        bq[ks] = ch < c ? xb[(size_t)ch * n + q] : 0.f;
+    }
+    const float sq_q = sqb[q];
+
+    pcc::BufferedTopK<K, kCap, T> tk;
+    tk.init(buf_d, buf_i, tid);
+
+    const int ntiles = (n + 31) / 32;
+    auto stage = [&](int t, int slot) {
+        float *dst = tile + slot * CP * 32;
+        const int j0 = t * 32;
+        for (int e = tid; e < CP * 32; e += T) {
+            const int ch = e >> 5, j = e & 31;
+            dst[e] = (ch < c && j0 + j < n) ? xb[(size_t)ch * n + j0 + j] : 0.f;
+        }
+        if (tid < 32) tsq[slot * 32 + tid] = (j0 + tid < n) ? sqb[j0 + tid] : __builtin_inff();
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int slot = t & 1;
+        if (t + 1 < ntiles) stage(t + 1, slot ^ 1);
+        const float *cur = tile + slot * CP * 32;
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            // A operand: candidate[row = lane&31][k = 2*ks + half]
+            const float a = cur[(2 * ks + half) * 32 + col];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[ks], acc, 0, 0, 0);
+        }
+        if (tk.must_flush(16)) tk.flush();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;  // candidate inside the tile
+            // reference CPU path: dist = -2*dot ; dist += |xj|^2 (column term) ; dist += |xi|^2 (row term)
+            const float d = (-2.0f * acc[r] + tsq[slot * 32 + row]) + sq_q;
+            tk.offer(d, t * 32 + row);
+        }
+        __syncthreads();
+    }
+    tk.flush();
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+        mrg_d[((w * 2 + half) * K + s) * 32 + col] = tk.top.d[s];
+        mrg_i[((w * 2 + half) * K + s) * 32 + col] = tk.top.i[s];
+    }
+    __syncthreads();
+    if (half == 0 && q_ok) {
+        // two-way merge of the half-wave lists; ties: lower candidate index first (the lists cover interleaved
+        // row groups, so compare indices explicitly)
+        const float *d0 = mrg_d + ((w * 2 + 0) * K) * 32 + col, *d1 = mrg_d + ((w * 2 + 1) * K) * 32 + col;
+        const int *i0 = mrg_i + ((w * 2 + 0) * K) * 32 + col, *i1 = mrg_i + ((w * 2 + 1) * K) * 32 + col;
+        int p0 = 0, p1 = 0;
+        int64_t *dst = indices + ((size_t)smp * n + q) * k;
+        for (int o = 0; o < k; o++) {
+            const float a = p0 < K ? d0[p0 * 32] : __builtin_inff();
+            const float bb = p1 < K ? d1[p1 * 32] : __builtin_inff();
+            const int ia = p0 < K ? i0[p0 * 32] : 0x7fffffff;
+            const int ib = p1 < K ? i1[p1 * 32] : 0x7fffffff;
+            const bool take0 = (a < bb) || (a == bb && ia < ib);
+            dst[o] = (int64_t)(take0 ? ia : ib);
+            p0 += take0 ? 1 : 0;
+            p1 += take0 ? 0 : 1;
+        }
+    }
+}
+
+template <int K>
+int launch_small(int b, int c, int n, int k, const float *x, int64_t *indices, hipStream_t st) {
+    pcc::ProfScope prof("knn_small_kernel", st);
+    hipLaunchKernelGGL((knn_small_kernel<K, 4>), dim3(pcc::ceil_div(n, 64), b), dim3(256), 0, st, c, n, k, x, indices);
+    return PCC_OK;
+}
+
+template <int K>
+int launch_mfma(int b, int c, int n, int k, const float *x, const float *sq, int64_t *indices, hipStream_t st) {
+    pcc::ProfScope prof("knn_mfma_kernel", st);
+    const dim3 grid(pcc::ceil_div(n, 128), b);
+    if (c <= 8) hipLaunchKernelGGL((knn_mfma_kernel<K, 8>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
+    else if (c <= 16) hipLaunchKernelGGL((knn_mfma_kernel<K, 16>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
+    else if (c <= 32) hipLaunchKernelGGL((knn_mfma_kernel<K, 32>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
+    else if (c <= 64) hipLaunchKernelGGL((knn_mfma_kernel<K, 64>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
+    else hipLaunchKernelGGL((knn_mfma_kernel<K, 128>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
+    return PCC_OK;
+}
+
+struct SqBuf {
+    float *p = nullptr;
+    hipStream_t st;
+    explicit SqBuf(hipStream_t s) : st(s) {}
+    ~SqBuf() {
+        if (p) (void)hipFreeAsync(p, st);
+    }
+};
+
+}  // namespace
+
+extern "C" int pcc_knn(int b, int c, int n, int k, const float *x, int64_t *indices, pcc_stream_t stream) {
+    pcc::clear_error();
+    if (b < 0 || c < 1 || n < 0 || k < 1) return pcc::invalid("knn: bad size");
+    if (b == 0 || n == 0) return PCC_OK;
+    if (k > n) return pcc::invalid("knn: k exceeds the number of points (torch.topk raises too)");
+    if (k > 32) return pcc::invalid("knn: k > 32 is not supported");
+    if (c > 128) return pcc::invalid("knn: more than 128 channels is not supported");
+    if (b > 65535) return pcc::invalid("knn: batch too large");
+    if (!x || !indices) return pcc::invalid("knn: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (c <= 3) {
+        if (k <= 4) launch_small<4>(b, c, n, k, x, indices, st);
+        else if (k <= 8) launch_small<8>(b, c, n, k, x, indices, st);
+        else if (k <= 16) launch_small<16>(b, c, n, k, x, indices, st);
+        else if (k <= 20) launch_small<20>(b, c, n, k, x, indices, st);
+        else if (k <= 25) launch_small<25>(b, c, n, k, x, indices, st);
+        else launch_small<32>(b, c, n, k, x, indices, st);
+        return pcc::check_launch("knn(small)");
+    }
+    SqBuf sq(st);
+    if (hipMallocAsync(reinterpret_cast<void **>(&sq.p), (size_t)b * n * sizeof(float), st) != hipSuccess) {
+        sq.p = nullptr;
+        (void)hipGetLastError();
+        pcc::set_error(PCC_ENOMEM, "knn: workspace hipMallocAsync failed");
+        return PCC_ENOMEM;
+    }
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(pcc::ceil_div(n, 256), b), dim3(256), 0, st, c, n, x, sq.p);
+    if (int rc = pcc::check_launch("knn(sqnorm)")) return rc;
+    if (k <= 4) launch_mfma<4>(b, c, n, k, x, sq.p, indices, st);
+    else if (k <= 8) launch_mfma<8>(b, c, n, k, x, sq.p, indices, st);
+    else if (k <= 16) launch_mfma<16>(b, c, n, k, x, sq.p, indices, st);
+    else if (k <= 20) launch_mfma<20>(b, c, n, k, x, sq.p, indices, st);
+    else if (k <= 25) launch_mfma<25>(b, c, n, k, x, sq.p, indices, st);
+    else launch_mfma<32>(b, c, n, k, x, sq.p, indices, st);
+    return pcc::check_launch("knn(mfma)");
+}

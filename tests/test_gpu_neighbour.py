@@ -1,0 +1,135 @@
+"""GPU parity tests of the kNN-graph primitives (HIP through the C ABI) vs the oracle and the vectors
+generated from the reference's own neighbour_ops.py functions."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_neighbour_ops.npz'), allow_pickle=False)
+
+
+def _x(seed, b, c, n, kind='normal'):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(b, c, n, generator=g) if kind == 'normal' else torch.rand(b, c, n, generator=g)).contiguous()
+
+
+@pytest.mark.parametrize('b,c,n,k', [(2, 3, 64, 4), (2, 3, 257, 20), (1, 3, 2048, 25), (2, 3, 2100, 25), (3, 1, 100, 8),
+                                       (2, 2, 333, 16), (1, 3, 25, 25), (2, 3, 40, 32), (32, 3, 2048, 4)])
+def test_knn_small_c_bit_exact(cuda, oracle_mod, b, c, n, k):
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    x = _x(b * 1000 + n + k, b, c, n, 'uniform')
+    idx = ops.knn(x.to(cuda), k).cpu().numpy()
+    if b * n > 20000:  # oracle on a slice only (it sorts every row)
+        sel = slice(0, 2)
+        exp = oracle_mod.knn_diff(x[sel].numpy(), k)
+        assert np.array_equal(idx[sel], exp)
+        exp_last = oracle_mod.knn_diff(x[-1:].numpy(), k)
+        assert np.array_equal(idx[-1:], exp_last)
+    else:
+        assert np.array_equal(idx, oracle_mod.knn_diff(x.numpy(), k))
+
+
+def test_knn_ties_ascending_index(cuda, oracle_mod):
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    base = _x(3, 1, 3, 50, 'uniform')
+    x = torch.cat([base] * 6, dim=2).contiguous()  # every point 6 times -> 6-way exact ties everywhere
+    idx = ops.knn(x.to(cuda), 8).cpu().numpy()
+    assert np.array_equal(idx, oracle_mod.knn_diff(x.numpy(), 8))
+    assert (idx[0, :, 0] == np.arange(300) % 50).all()  # lowest copy first
+
+
+@pytest.mark.parametrize('b,c,n,k', [(2, 4, 64, 4), (2, 6, 200, 16), (2, 64, 257, 25), (1, 64, 2048, 25), (2, 128, 300, 20),
+                                       (1, 128, 2048, 25), (2, 17, 131, 8), (2, 64, 2050, 25)])
+def test_knn_mfma_vs_oracle(cuda, oracle_mod, b, c, n, k):
+    """c >= 4: expanded form on the f32 MFMA pipe.  v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain, so the
+    distances (and therefore the sorted index lists) must match the sequential-fma oracle bit for bit."""
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    x = _x(c * 7 + n, b, c, n)
+    idx = ops.knn(x.to(cuda), k).cpu().numpy()
+    exp = oracle_mod.knn_expanded(x.numpy(), k)
+    assert np.array_equal(idx, exp)
+
+
+@pytest.mark.parametrize('tag', ['c3', 'c3k20', 'c64'])
+def test_knn_vs_reference_fixture(cuda, tag):
+    """Against the reference's own torch_knn outputs: identical neighbour lists up to near ties."""
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+    from tests.test_neighbour_oracle import _near_tie_ok
+
+    x, k = GOLD[f'{tag}_x'], int(GOLD[f'{tag}_k'])
+    ref_idx, ref_dist = GOLD[f'{tag}_knn'], GOLD[f'{tag}_selfdist']
+    idx = ops.knn(torch.from_numpy(x).to(cuda), k).cpu().numpy()
+    bad = sum(not _near_tie_ok(ref_dist[b, q], idx[b, q], ref_idx[b, q], 1e-4)
+              for b in range(x.shape[0]) for q in range(x.shape[2]))
+    assert bad == 0
+    exact = (idx == ref_idx).mean()
+    assert exact > 0.995, exact
+
+
+@pytest.mark.parametrize('b,c,n,k', [(2, 3, 64, 4), (2, 64, 257, 20), (1, 128, 512, 25), (3, 5, 100, 7)])
+def test_graph_ops_forward_backward(cuda, b, c, n, k):
+    from oracle import neighbour_oracle as no
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    x = _x(n + c, b, c, n)
+    idx = ops.knn(x.to(cuda), k)
+    for name, fn_gpu, fn_ref in (
+        ('gather', lambda t: ops.get_neighbours(t, idx, k)[1], lambda t: no.gather_neighbours(t, idx.cpu())),
+        ('features', lambda t: ops.get_graph_features(t, idx, k)[1], lambda t: no.graph_features(t, idx.cpu())),
+        ('maxpool', lambda t: ops.graph_max_pooling(t, idx, k), lambda t: no.graph_max_pooling(t, idx.cpu())),
+        ('globalmax', ops.global_max_pool, lambda t: t.max(dim=2)[0]),
+    ):
+        tg = x.to(cuda).requires_grad_(True)
+        tr = x.clone().requires_grad_(True)
+        og, orf = fn_gpu(tg), fn_ref(tr)
+        assert torch.equal(og.cpu(), orf), name  # pure copies / max: exact
+        w = torch.randn(orf.shape, generator=torch.Generator().manual_seed(1))
+        (og * w.to(cuda)).sum().backward()
+        (orf * w).sum().backward()
+        torch.testing.assert_close(tg.grad.cpu(), tr.grad, rtol=1e-5, atol=1e-5, msg=name)
+
+
+def test_graph_ops_vs_reference_fixture(cuda):
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    for tag in ('c3', 'c3k20'):
+        x = torch.from_numpy(GOLD[f'{tag}_x']).to(cuda)
+        idx = torch.from_numpy(GOLD[f'{tag}_knn']).to(cuda)
+        k = int(GOLD[f'{tag}_k'])
+        assert torch.equal(ops.get_graph_features(x, idx, k)[1].cpu(), torch.from_numpy(GOLD[f'{tag}_graph_features']))
+        assert torch.equal(ops.graph_max_pooling(x, idx, k).cpu(), torch.from_numpy(GOLD[f'{tag}_max_pool']))
+    x = torch.from_numpy(GOLD['c64_x']).to(cuda)
+    idx = torch.from_numpy(GOLD['c64_knn']).to(cuda)
+    assert torch.equal(ops.graph_max_pooling(x, idx, 25).cpu(), torch.from_numpy(GOLD['c64_max_pool']))
+
+
+def test_graph_filtering(cuda):
+    from oracle import neighbour_oracle as no
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    out = ops.graph_filtering(torch.from_numpy(GOLD['filt_x']).to(cuda), k=4)
+    torch.testing.assert_close(out.cpu(), torch.from_numpy(GOLD['filt_out']), rtol=1e-5, atol=1e-6)
+    # gradient flows through the gathered neighbours exactly as in the torch composition
+    x = _x(5, 2, 3, 300, 'uniform')
+    tg = x.to(cuda).requires_grad_(True)
+    ops.graph_filtering(tg, 4).pow(2).sum().backward()
+    tr = x.clone().requires_grad_(True)
+    idx = ops.knn(x.to(cuda), 4).cpu()
+    no.graph_filtering(tr, idx).pow(2).sum().backward()
+    torch.testing.assert_close(tg.grad.cpu(), tr.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_global_max_mean_pool(cuda):
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    x = _x(9, 4, 96, 1000)
+    out = ops.global_max_mean_pool(x.to(cuda)).cpu()
+    assert torch.equal(out[:, :96], x.max(dim=2)[0])
+    torch.testing.assert_close(out[:, 96:], x.mean(dim=2), rtol=1e-5, atol=1e-6)
