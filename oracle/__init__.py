@@ -193,3 +193,30 @@ def knn_expanded(x, k: int, return_dist: bool = False):
     dist = np.zeros((b, n, n), np.float32) if return_dist else None
     lib().oracle_knn_expanded(b, c, n, int(k), _p(x), _p(idx, _i64p), _p(dist) if return_dist else None)
     return (idx, dist) if return_dist else idx
+
+
+# ---- auction EMD (auction_oracle.c) ---------------------------------------------------------------------------------
+
+
+def auction_forward(xyz1, xyz2, eps: float, iters: int):
+    """-> dist[B,n] f32, assignment[B,n] i32, price[B,n] f32 (emd_cuda.cu:227-281, deterministic interpretation)."""
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    b, n, m = _dims(xyz1, xyz2)
+    assert n == m
+    dist = np.zeros((b, n), np.float32)
+    ass = np.zeros((b, n), np.int32)
+    price = np.zeros((b, n), np.float32)
+    lib().oracle_auction_forward.restype = ctypes.c_int
+    rc = lib().oracle_auction_forward(b, n, _p(xyz1), _p(xyz2), ctypes.c_float(eps), int(iters), _p(dist),
+                                      _p(ass, _i32p), _p(price))
+    if rc != 1:
+        raise ValueError('auction: invalid input (n % 1024, b <= 512, iters >= 1)')
+    return dist, ass, price
+
+
+def auction_backward(xyz1, xyz2, grad_dist, assignment):
+    xyz1, xyz2, g, a = _f(xyz1), _f(xyz2), _f(grad_dist), _i(assignment)
+    b, n, _ = _dims(xyz1, xyz2)
+    out = np.zeros((b, n, 3), np.float32)
+    lib().oracle_auction_backward(b, n, _p(xyz1), _p(xyz2), _p(g), _p(a, _i32p), _p(out))
+    return out
