@@ -34,7 +34,8 @@ int pcc_knn(int b, int c, int n, int k, const float *x, int64_t *indices, pcc_st
 int pcc_gather_neighbours(int b, int c, int n, int k, const float *x, const int64_t *indices, float *out,
                           pcc_stream_t stream);
 /* backward of the gather: grad_x[b,c,t] = sum over (n,j) with indices[b,n,j]==t of grad_out[b,c,n,j].
- * grad_x is overwritten. */
+ * grad_x is overwritten.  Accumulated in per-workgroup LDS bins (ds_add_f32): like the torch scatter_add the
+ * reference's gather backward runs, the float summation order is not fixed. */
 int pcc_gather_neighbours_bwd(int b, int c, int n, int k, const int64_t *indices, const float *grad_out,
                               float *grad_x, pcc_stream_t stream);
 

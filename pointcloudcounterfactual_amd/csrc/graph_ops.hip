@@ -2,202 +2,136 @@
 //
 // Replaces the torch.gather / cat / max compositions of the reference's src/utils/neighbour_ops.py:85-119
 // and the global pooling of src/module/encoders.py:58 / classifier.py:63-64.  All of them are HBM-bound
-// index-driven copies; the kernels keep every global access coalesced along the (n,k) axis, reuse one index
-// load for all channels of a block, and do the backward scatter WITHOUT float atomics: a reverse adjacency
-// (for every target point, the sorted list of edges that point to it) is built once per call from the
-// int64 index tensor and shared by all channels, so gradients are bit-reproducible.
+// index-driven copies; the kernels keep every global access coalesced along the (n,k) axis and reuse one index
+// load for all channels of a block; the backward scatter accumulates into per-workgroup LDS bins (no global
+// atomics).
 #include "pcc_common.hpp"
 #include "pcc_neighbour.h"
 
 namespace {
 
-constexpr int kChanBlock = 8;  // channels handled per thread (index reuse)
-
-// MODE 0: gather            out[b,c,n,j]      = x[b,c,idx]
-// MODE 1: graph features    out[b,c,n,j]      = x[b,c,idx] - x[b,c,n] ; out[b,C+c,n,j] = x[b,c,n]
-template <int MODE>
-__global__ __launch_bounds__(256) void gather_kernel(int c, int n, int k, const float *__restrict__ x,
-                                                      const int64_t *__restrict__ indices, float *__restrict__ out) {
-    const int smp = blockIdx.z;
+// Forward: a workgroup owns CB channels of one sample, stages those rows of x in LDS (the gathers then hit
+// LDS instead of 64 different cache lines per wave-instruction) and streams the (n,k) index list.
+//   MODE 0: gather            out[b,c,n,j]  = x[b,c,idx]
+//   MODE 1: graph features    out[b,c,n,j]  = x[b,c,idx] - x[b,c,n] ; out[b,C+c,n,j] = x[b,c,n]
+//   MODE 2: max over k        out[b,c,n]    = max_j x[b,c,idx[n,j]] (+ argmax, first maximum like torch.max)
+template <int MODE, int CB>
+__global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, const float *__restrict__ x,
+                                                           const int64_t *__restrict__ indices, float *__restrict__ out,
+                                                           int32_t *__restrict__ argmax) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];  // [CB][n]
+    const int smp = blockIdx.y, c0 = blockIdx.x * CB;
+    const int tid = threadIdx.x, T = 1024;
     const size_t nk = (size_t)n * k;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nk) return;
-    const int c0 = blockIdx.y * kChanBlock;
-    const int64_t t = indices[(size_t)smp * nk + e];
-    const int i = (int)(e / k);
-    const float *xb = x + (size_t)smp * c * n;
-    const int out_c = MODE == 1 ? 2 * c : c;
-    float *ob = out + (size_t)smp * out_c * nk;
+    const float *xb = x + ((size_t)smp * c + c0) * n;
+    const int cb = min(CB, c - c0);
+    for (int i = tid; i < cb * n; i += T) rows[i] = xb[i];
+    __syncthreads();
+    const int64_t *ib = indices + (size_t)smp * nk;
+    if (MODE == 2) {
+        for (int i = tid; i < n; i += T) {
+            float best[CB];
+            int bj[CB];
 #pragma unroll
-    for (int cc = 0; cc < kChanBlock; cc++) {
-        const int ch = c0 + cc;
-        if (ch >= c) break;
-        const float nb = xb[(size_t)ch * n + t];
-        if (MODE == 0) {
-            ob[(size_t)ch * nk + e] = nb;
-        } else {
-            const float self = xb[(size_t)ch * n + i];
-            ob[(size_t)ch * nk + e] = nb - self;
-            ob[(size_t)(c + ch) * nk + e] = self;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void max_pool_kernel(int c, int n, int k, const float *__restrict__ x,
-                                                        const int64_t *__restrict__ indices, float *__restrict__ out,
-                                                        int32_t *__restrict__ argmax) {
-    const int smp = blockIdx.z;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int c0 = blockIdx.y * kChanBlock;
-    const float *xb = x + (size_t)smp * c * n;
-    const int64_t *ib = indices + ((size_t)smp * n + i) * k;
-    float best[kChanBlock];
-    int bj[kChanBlock];
+            for (int cc = 0; cc < CB; cc++) {
+                best[cc] = -__builtin_inff();
+                bj[cc] = 0;
+            }
+            for (int j = 0; j < k; j++) {
+                const int t = (int)ib[(size_t)i * k + j];
 #pragma unroll
-    for (int cc = 0; cc < kChanBlock; cc++) {
-        best[cc] = -__builtin_inff();
-        bj[cc] = 0;
-    }
-    for (int j = 0; j < k; j++) {
-        const int64_t t = ib[j];
+                for (int cc = 0; cc < CB; cc++) {
+                    if (cc < cb) {
+                        const float v = rows[cc * n + t];
+                        const bool gt = (j == 0) || v > best[cc];
+                        best[cc] = gt ? v : best[cc];
+                        bj[cc] = gt ? j : bj[cc];
+                    }
+                }
+            }
 #pragma unroll
-        for (int cc = 0; cc < kChanBlock; cc++) {
-            const int ch = c0 + cc;
-            if (ch < c) {
-                const float v = xb[(size_t)ch * n + t];
-                const bool gt = (j == 0) || v > best[cc];  // first maximum wins, like torch.max
-                best[cc] = gt ? v : best[cc];
-                bj[cc] = gt ? j : bj[cc];
+            for (int cc = 0; cc < CB; cc++) {
+                if (cc < cb) {
+                    out[((size_t)smp * c + c0 + cc) * n + i] = best[cc];
+                    if (argmax) argmax[((size_t)smp * c + c0 + cc) * n + i] = bj[cc];
+                }
             }
         }
-    }
+    } else {
+        const int out_c = MODE == 1 ? 2 * c : c;
+        float *ob = out + (size_t)smp * out_c * nk;
+        for (size_t e = tid; e < nk; e += T) {
+            const int t = (int)ib[e];
+            const int i = (int)(e / k);
 #pragma unroll
-    for (int cc = 0; cc < kChanBlock; cc++) {
-        const int ch = c0 + cc;
-        if (ch < c) {
-            out[((size_t)smp * c + ch) * n + i] = best[cc];
-            if (argmax) argmax[((size_t)smp * c + ch) * n + i] = bj[cc];
-        }
-    }
-}
-
-// ---- reverse adjacency -----------------------------------------------------------------------------
-// counts[b][t] = #edges e=(i,j) with indices[b,i,j]==t ; offs = exclusive scan ; edges sorted ascending.
-__global__ __launch_bounds__(256) void rev_count_kernel(int n, int k, const int64_t *__restrict__ indices,
-                                                         int *__restrict__ counts) {
-    const int smp = blockIdx.y;
-    const size_t nk = (size_t)n * k;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nk) return;
-    atomicAdd(&counts[(size_t)smp * n + indices[(size_t)smp * nk + e]], 1);
-}
-
-__global__ __launch_bounds__(1024) void rev_scan_kernel(int n, const int *__restrict__ counts, int *__restrict__ offs,
-                                                         int *__restrict__ cursor) {
-    // one workgroup per sample: exclusive scan of counts -> offs[0..n], cursor = offs
-    __shared__ int part[1024];
-    const int smp = blockIdx.x, tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int beg = tid * per, end = min(beg + per, n);
-    int s = 0;
-    for (int i = beg; i < end; i++) s += counts[(size_t)smp * n + i];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int run = tid ? part[tid - 1] : 0;
-    for (int i = beg; i < end; i++) {
-        offs[(size_t)smp * (n + 1) + i] = run;
-        cursor[(size_t)smp * n + i] = run;
-        run += counts[(size_t)smp * n + i];
-    }
-    if (tid == 1023) offs[(size_t)smp * (n + 1) + n] = part[1023];
-}
-
-__global__ __launch_bounds__(256) void rev_fill_kernel(int n, int k, const int64_t *__restrict__ indices,
-                                                        int *__restrict__ cursor, int *__restrict__ edges) {
-    const int smp = blockIdx.y;
-    const size_t nk = (size_t)n * k;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nk) return;
-    const int t = (int)indices[(size_t)smp * nk + e];
-    const int pos = atomicAdd(&cursor[(size_t)smp * n + t], 1);
-    edges[(size_t)smp * nk + pos] = (int)e;
-}
-
-__global__ __launch_bounds__(256) void rev_sort_kernel(int n, int k, const int *__restrict__ offs,
-                                                        int *__restrict__ edges) {
-    // ascending edge order inside every target's list (insertion sort; lists average k entries)
-    const int smp = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const int beg = offs[(size_t)smp * (n + 1) + t], end = offs[(size_t)smp * (n + 1) + t + 1];
-    int *lst = edges + (size_t)smp * n * k;
-    for (int a = beg + 1; a < end; a++) {
-        const int v = lst[a];
-        int p = a - 1;
-        while (p >= beg && lst[p] > v) {
-            lst[p + 1] = lst[p];
-            p--;
-        }
-        lst[p + 1] = v;
-    }
-}
-
-// MODE 0: grad_x[b,c,t] = sum_{e in rev(t)} g[b,c,e]
-// MODE 1: ... + sum_j (g[b,C+c,t,j] - g[b,c,t,j])                      (graph features)
-// MODE 2: grad_x[b,c,t] = sum_{e=(i,j) in rev(t), argmax[b,c,i]==j} g[b,c,i]   (max pool)
-template <int MODE>
-__global__ __launch_bounds__(256) void scatter_bwd_kernel(int c, int n, int k, const int *__restrict__ offs,
-                                                           const int *__restrict__ edges,
-                                                           const int32_t *__restrict__ argmax,
-                                                           const float *__restrict__ g, float *__restrict__ grad_x) {
-    const int smp = blockIdx.z;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const int c0 = blockIdx.y * kChanBlock;
-    const size_t nk = (size_t)n * k;
-    const int beg = offs[(size_t)smp * (n + 1) + t], end = offs[(size_t)smp * (n + 1) + t + 1];
-    const int *lst = edges + (size_t)smp * nk;
-    const int gc = MODE == 1 ? 2 * c : c;
-    float acc[kChanBlock];
-#pragma unroll
-    for (int cc = 0; cc < kChanBlock; cc++) acc[cc] = 0.f;
-    for (int a = beg; a < end; a++) {
-        const int e = lst[a];
-#pragma unroll
-        for (int cc = 0; cc < kChanBlock; cc++) {
-            const int ch = c0 + cc;
-            if (ch < c) {
-                if (MODE == 2) {
-                    const int i = e / k, j = e - i * k;
-                    if (argmax[((size_t)smp * c + ch) * n + i] == j) acc[cc] += g[((size_t)smp * c + ch) * n + i];
-                } else {
-                    acc[cc] += g[((size_t)smp * gc + ch) * nk + e];
+            for (int cc = 0; cc < CB; cc++) {
+                if (cc < cb) {
+                    const float nb = rows[cc * n + t];
+                    if (MODE == 0) {
+                        ob[(size_t)(c0 + cc) * nk + e] = nb;
+                    } else {
+                        const float self = rows[cc * n + i];
+                        ob[(size_t)(c0 + cc) * nk + e] = nb - self;
+                        ob[(size_t)(c + c0 + cc) * nk + e] = self;
+                    }
                 }
             }
         }
     }
-    if (MODE == 1) {
-        for (int j = 0; j < k; j++) {
+}
+
+// ---- backward scatter --------------------------------------------------------------------------------
+// grad_x[b,c,t] = sum over edges e=(i,j) with indices[b,i,j]==t of g[b,c,e]  (+ the self terms).
+// A workgroup owns CB channels of one sample and keeps their n gradient bins in LDS; it streams the edge
+// list with fully coalesced reads of `indices` and of the CB gradient rows and accumulates with ds_add_f32.
+// kNN graphs in feature space are hubby (one point can be the neighbour of thousands), which ruins any
+// one-thread-per-target gather; the bin scatter is insensitive to that.  Like torch's scatter_add (what the
+// reference's gather backward runs) the float summation order is not fixed.
+//   MODE 0: gather            MODE 1: graph features (adds sum_j g[C+c][i,j] - g[c][i,j] to bin i)
+//   MODE 2: max pool (only the argmax edge of every (c,i) carries gradient)
+template <int MODE, int CB>
+__global__ __launch_bounds__(1024) void scatter_lds_kernel(int c, int n, int k, const int64_t *__restrict__ indices,
+                                                            const int32_t *__restrict__ argmax,
+                                                            const float *__restrict__ g, float *__restrict__ grad_x) {
+    extern __shared__ __attribute__((aligned(16))) float bins[];  // [CB][n]
+    const int smp = blockIdx.y, c0 = blockIdx.x * CB;
+    const int tid = threadIdx.x, T = 1024;
+    const size_t nk = (size_t)n * k;
+    const int64_t *ib = indices + (size_t)smp * nk;
+    const int gc = MODE == 1 ? 2 * c : c;
+    for (int i = tid; i < CB * n; i += T) bins[i] = 0.f;
+    __syncthreads();
+    if (MODE == 2) {
+        for (int i = tid; i < n; i += T) {
 #pragma unroll
-            for (int cc = 0; cc < kChanBlock; cc++) {
+            for (int cc = 0; cc < CB; cc++) {
                 const int ch = c0 + cc;
-                if (ch < c)
-                    acc[cc] += g[((size_t)smp * gc + c + ch) * nk + (size_t)t * k + j] -
-                               g[((size_t)smp * gc + ch) * nk + (size_t)t * k + j];
+                if (ch < c) {
+                    const int j = argmax[((size_t)smp * c + ch) * n + i];
+                    const int t = (int)ib[(size_t)i * k + j];
+                    atomicAdd(&bins[cc * n + t], g[((size_t)smp * c + ch) * n + i]);
+                }
+            }
+        }
+    } else {
+        for (size_t e = tid; e < nk; e += T) {
+            const int t = (int)ib[e];
+            const int i = (int)(e / k);
+#pragma unroll
+            for (int cc = 0; cc < CB; cc++) {
+                const int ch = c0 + cc;
+                if (ch < c) {
+                    const float v = g[((size_t)smp * gc + ch) * nk + e];
+                    atomicAdd(&bins[cc * n + t], v);
+                    if (MODE == 1) atomicAdd(&bins[cc * n + i], g[((size_t)smp * gc + c + ch) * nk + e] - v);
+                }
             }
         }
     }
-#pragma unroll
-    for (int cc = 0; cc < kChanBlock; cc++) {
-        const int ch = c0 + cc;
-        if (ch < c) grad_x[((size_t)smp * c + ch) * n + t] = acc[cc];
+    __syncthreads();
+    for (int i = tid; i < CB * n; i += T) {
+        const int cc = i / n, t = i - cc * n;
+        if (c0 + cc < c) grad_x[((size_t)smp * c + c0 + cc) * n + t] = bins[i];
     }
 }
 
@@ -235,63 +169,63 @@ __global__ __launch_bounds__(256) void global_pool_kernel(int rows, int n, const
     }
 }
 
-struct Scratch {
-    void *p = nullptr;
-    hipStream_t st;
-    explicit Scratch(hipStream_t s) : st(s) {}
-    int alloc(size_t bytes) {
-        if (hipMallocAsync(&p, bytes, st) != hipSuccess) {
-            p = nullptr;
-            (void)hipGetLastError();
-            pcc::set_error(PCC_ENOMEM, "graph ops: workspace hipMallocAsync failed");
-            return PCC_ENOMEM;
-        }
-        return PCC_OK;
-    }
-    ~Scratch() {
-        if (p) (void)hipFreeAsync(p, st);
-    }
-};
-
 int check(const char *who, int b, int c, int n, int k) {
     if (b < 0 || c < 1 || n < 0 || k < 1) return pcc::invalid(who);
     if (b > 65535 || (long long)n * k > 0x7fffffffLL) return pcc::invalid(who);
     return PCC_OK;
 }
 
-// Build offs[b][n+1] and sorted edges[b][n*k] in `ws` (ints): layout counts|cursor|offs|edges.
-int build_reverse(int b, int n, int k, const int64_t *indices, int *ws, int **offs_out, int **edges_out,
-                  hipStream_t st) {
-    const size_t nk = (size_t)n * k;
-    int *counts = ws;
-    int *cursor = counts + (size_t)b * n;
-    int *offs = cursor + (size_t)b * n;
-    int *edges = offs + (size_t)b * (n + 1);
-    if (hipMemsetAsync(counts, 0, (size_t)b * n * sizeof(int), st) != hipSuccess) return pcc::invalid("memset failed");
-    const dim3 ge((unsigned)((nk + 255) / 256), b);
-    hipLaunchKernelGGL(rev_count_kernel, ge, dim3(256), 0, st, n, k, indices, counts);
-    hipLaunchKernelGGL(rev_scan_kernel, dim3(b), dim3(1024), 0, st, n, counts, offs, cursor);
-    hipLaunchKernelGGL(rev_fill_kernel, ge, dim3(256), 0, st, n, k, indices, cursor, edges);
-    hipLaunchKernelGGL(rev_sort_kernel, dim3(pcc::ceil_div(n, 256), b), dim3(256), 0, st, n, k, offs, edges);
-    *offs_out = offs;
-    *edges_out = edges;
-    return pcc::check_launch("reverse adjacency");
-}
-
-size_t reverse_bytes(int b, int n, int k) {
-    return ((size_t)b * n * 2 + (size_t)b * (n + 1) + (size_t)b * n * k) * sizeof(int);
+template <int MODE>
+int gather_fwd(int b, int c, int n, int k, const float *x, const int64_t *indices, float *out, int32_t *argmax,
+               hipStream_t st, const char *what) {
+    int cb = 8;
+    while (cb > 1 && (size_t)cb * n * sizeof(float) > 64 * 1024) cb >>= 1;
+    const size_t lds = (size_t)cb * n * sizeof(float);
+    if (lds > 160 * 1024) return pcc::invalid("graph op: n too large for the LDS row tile");
+    const dim3 grid(pcc::ceil_div(c, cb), b);
+    pcc::ProfScope prof(what, st);
+#define PCC_LAUNCH(CB)                                                                                              \
+    do {                                                                                                            \
+        static bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gather_lds_kernel<MODE, CB>),         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; \
+        (void)attr;                                                                                                 \
+        hipLaunchKernelGGL((gather_lds_kernel<MODE, CB>), grid, dim3(1024), lds, st, c, n, k, x, indices, out, argmax); \
+    } while (0)
+    switch (cb) {
+    case 8: PCC_LAUNCH(8); break;
+    case 4: PCC_LAUNCH(4); break;
+    case 2: PCC_LAUNCH(2); break;
+    default: PCC_LAUNCH(1); break;
+    }
+#undef PCC_LAUNCH
+    return pcc::check_launch(what);
 }
 
 template <int MODE>
 int scatter_bwd(int b, int c, int n, int k, const int64_t *indices, const int32_t *argmax, const float *g,
                 float *grad_x, hipStream_t st, const char *what) {
-    Scratch ws(st);
-    if (int rc = ws.alloc(reverse_bytes(b, n, k))) return rc;
-    int *offs, *edges;
-    if (int rc = build_reverse(b, n, k, indices, static_cast<int *>(ws.p), &offs, &edges, st)) return rc;
+    // channels per workgroup: as many as fit 64 KiB of bins (two workgroups per CU)
+    int cb = 8;
+    while (cb > 1 && (size_t)cb * n * sizeof(float) > 64 * 1024) cb >>= 1;
+    const size_t lds = (size_t)cb * n * sizeof(float);
+    if (lds > 160 * 1024) return pcc::invalid("graph op backward: n too large for the LDS bins");
+    const dim3 grid(pcc::ceil_div(c, cb), b);
     pcc::ProfScope prof(what, st);
-    hipLaunchKernelGGL((scatter_bwd_kernel<MODE>), dim3(pcc::ceil_div(n, 256), pcc::ceil_div(c, kChanBlock), b), dim3(256),
-                       0, st, c, n, k, offs, edges, argmax, g, grad_x);
+#define PCC_LAUNCH(CB)                                                                                               \
+    do {                                                                                                             \
+        static bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(scatter_lds_kernel<MODE, CB>),         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; \
+        (void)attr;                                                                                                  \
+        hipLaunchKernelGGL((scatter_lds_kernel<MODE, CB>), grid, dim3(1024), lds, st, c, n, k, indices, argmax, g,   \
+                           grad_x);                                                                                  \
+    } while (0)
+    switch (cb) {
+    case 8: PCC_LAUNCH(8); break;
+    case 4: PCC_LAUNCH(4); break;
+    case 2: PCC_LAUNCH(2); break;
+    default: PCC_LAUNCH(1); break;
+    }
+#undef PCC_LAUNCH
     return pcc::check_launch(what);
 }
 
@@ -305,11 +239,7 @@ int pcc_gather_neighbours(int b, int c, int n, int k, const float *x, const int6
     if (int rc = check("gather_neighbours: bad size", b, c, n, k)) return rc;
     if (b == 0 || n == 0) return PCC_OK;
     if (!x || !indices || !out) return pcc::invalid("gather_neighbours: null pointer");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    pcc::ProfScope prof("gather_kernel<gather>", st);
-    hipLaunchKernelGGL((gather_kernel<0>), dim3((unsigned)(((size_t)n * k + 255) / 256), pcc::ceil_div(c, kChanBlock), b),
-                       dim3(256), 0, st, c, n, k, x, indices, out);
-    return pcc::check_launch("gather_neighbours");
+    return gather_fwd<0>(b, c, n, k, x, indices, out, nullptr, static_cast<hipStream_t>(stream), "gather_lds_kernel<gather>");
 }
 
 int pcc_graph_features(int b, int c, int n, int k, const float *x, const int64_t *indices, float *out,
@@ -318,11 +248,7 @@ int pcc_graph_features(int b, int c, int n, int k, const float *x, const int64_t
     if (int rc = check("graph_features: bad size", b, c, n, k)) return rc;
     if (b == 0 || n == 0) return PCC_OK;
     if (!x || !indices || !out) return pcc::invalid("graph_features: null pointer");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    pcc::ProfScope prof("gather_kernel<features>", st);
-    hipLaunchKernelGGL((gather_kernel<1>), dim3((unsigned)(((size_t)n * k + 255) / 256), pcc::ceil_div(c, kChanBlock), b),
-                       dim3(256), 0, st, c, n, k, x, indices, out);
-    return pcc::check_launch("graph_features");
+    return gather_fwd<1>(b, c, n, k, x, indices, out, nullptr, static_cast<hipStream_t>(stream), "gather_lds_kernel<features>");
 }
 
 int pcc_graph_max_pool(int b, int c, int n, int k, const float *x, const int64_t *indices, float *out,
@@ -331,11 +257,7 @@ int pcc_graph_max_pool(int b, int c, int n, int k, const float *x, const int64_t
     if (int rc = check("graph_max_pool: bad size", b, c, n, k)) return rc;
     if (b == 0 || n == 0) return PCC_OK;
     if (!x || !indices || !out) return pcc::invalid("graph_max_pool: null pointer");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    pcc::ProfScope prof("max_pool_kernel", st);
-    hipLaunchKernelGGL(max_pool_kernel, dim3(pcc::ceil_div(n, 256), pcc::ceil_div(c, kChanBlock), b), dim3(256), 0, st, c, n,
-                       k, x, indices, out, argmax);
-    return pcc::check_launch("graph_max_pool");
+    return gather_fwd<2>(b, c, n, k, x, indices, out, argmax, static_cast<hipStream_t>(stream), "gather_lds_kernel<maxpool>");
 }
 
 int pcc_gather_neighbours_bwd(int b, int c, int n, int k, const int64_t *indices, const float *grad_out,
