@@ -20,6 +20,10 @@
 //                                                | the single rounded product is the same real number
 //   matchcost / grad re-read match 3x            | cost: one read; grads: one read each, deterministic
 //                                                | two-stage reductions (no float atomics)
+//   every pass evaluates all n*m pairs           | both clouds are Morton-sorted once per call (LDS bitonic
+//                                                | sort); at the fine levels a wave skips a 16-candidate
+//                                                | block when the box distance to its owner tile makes every
+//                                                | exp2(level*d2) underflow to exactly 0 (same result, less work)
 //
 // Rooflines: the 19 phase launches and the materialise pass are f32-VALU/transcendental
 // bound (10 / 14 / 60 issue slots per pair); matchcost and the two gradient kernels are HBM bound
@@ -59,30 +63,39 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // ---------------------------------------------------------------------------------------------------
 enum Phase { PH_A = 0, PH_B = 1, PH_CA = 2, PH_C = 3 };
 
+constexpr int kBox = 16;          // points per bounding-box block (sorted order)
+constexpr float kZeroExp = 151.f; // exp2(x) == 0 exactly for x <= -150 (below the smallest f32 subnormal)
+
 struct PhaseArgs {
     int n_own, n_cand, tiles;          // tiles = ceil(n_own / (64 R))
-    const float *own_xyz, *cand_xyz;   // [b, n_own, 3], [b, n_cand, 3]
-    const float *w0, *w1;              // per-candidate weights (w0 may be null => w0c)
+    int own_n4, cand_n4, own_nb, cand_nb;
+    const float *own_soa, *cand_soa;   // [b][3][n4] Hilbert-sorted coordinates
+    const float *own_box, *cand_box;   // [b][nb][8]  (min xyz, pad, max xyz, pad) per 16 sorted points
+    const float *w0, *w1;              // per-candidate weights in sorted order (w0 may be null => w0c)
     long long w0_stride, w1_stride;    // per-sample strides in floats
     float w0c;
     float c0, c1;
+    float cut2;                        // skip a candidate block when its box is farther than sqrt(cut2)
     int first;                         // first level: remain* still hold their initial constants
+    int level;                         // 0..8 (host bookkeeping only)
     float multiL, multiR;
-    // epilogue operands, all indexed [sample * stride + owner]
+    // epilogue operands, all indexed [sample * stride + owner (sorted position)]
     float *remain;                     // remainL (CA/C) or remainR (B)
     long long remain_stride;
     const float *ratio_in;             // CA/C: ratioL_i
     float *ratio_out;                  // A: ratioL_0 ; B: ratioR_i ; CA: ratioL_{i+1}
     long long ratio_stride;            // per-sample stride of the level arrays
+    int *dbg;                          // optional [2] counters: blocks visited / skipped (debug builds of the host)
 };
 
-template <int MODE, int R, int S, int CH>
+template <int MODE, int R, int S, int CH, bool CULL>
 __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     constexpr int T = 64 * S;
     constexpr int TQ = 64 * R;
     constexpr int NW = (MODE == PH_CA) ? 2 : 1;
     constexpr bool W0_CONST = (MODE == PH_A);
     __shared__ __attribute__((aligned(16))) float lds_c[(3 + NW) * CH];  // x | y | z | w0 | (w1)
+    __shared__ __attribute__((aligned(16))) float lds_bb[CULL ? (CH / kBox) * 8 : 8];
     __shared__ float red[NW][S][TQ];
 
     const int tid = threadIdx.x;
@@ -90,8 +103,8 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int smp = blockIdx.x / a.tiles;
     const int tile = blockIdx.x - smp * a.tiles;
-    const float *O = a.own_xyz + (size_t)smp * a.n_own * 3;
-    const float *C = a.cand_xyz + (size_t)smp * a.n_cand * 3;
+    const float *O = a.own_soa + (size_t)smp * 3 * a.own_n4;
+    const float *C = a.cand_soa + (size_t)smp * 3 * a.cand_n4;
     const float *W0 = W0_CONST ? nullptr : a.w0 + (size_t)smp * a.w0_stride;
     const float *W1 = (NW == 2) ? a.w1 + (size_t)smp * a.w1_stride : nullptr;
 
@@ -100,63 +113,117 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     for (int r = 0; r < R; r++) {
         int o = tile * TQ + r * 64 + lane;
         o = o < a.n_own ? o : a.n_own - 1;
-        ox[r] = O[o * 3 + 0];
-        oy[r] = O[o * 3 + 1];
-        oz[r] = O[o * 3 + 2];
+        ox[r] = O[o];
+        oy[r] = O[a.own_n4 + o];
+        oz[r] = O[2 * a.own_n4 + o];
         s0[r] = 0.f;
         s1[r] = 0.f;
+    }
+    // bounding boxes of the R groups of 64 owners this workgroup holds (wave-uniform): each is the union of
+    // four 16-point block boxes of the sorted order
+    float olx[R], oly[R], olz[R], ohx[R], ohy[R], ohz[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        olx[r] = oly[r] = olz[r] = __builtin_inff();
+        ohx[r] = ohy[r] = ohz[r] = -__builtin_inff();
+        if (CULL) {
+            const float *ob = a.own_box + (size_t)smp * a.own_nb * 8;
+            const int b0 = (tile * TQ + r * 64) / kBox;
+            const int b1 = min(b0 + 64 / kBox, a.own_nb);
+            for (int bb = b0; bb < b1; bb++) {
+                olx[r] = fminf(olx[r], ob[bb * 8 + 0]);
+                oly[r] = fminf(oly[r], ob[bb * 8 + 1]);
+                olz[r] = fminf(olz[r], ob[bb * 8 + 2]);
+                ohx[r] = fmaxf(ohx[r], ob[bb * 8 + 4]);
+                ohy[r] = fmaxf(ohy[r], ob[bb * 8 + 5]);
+                ohz[r] = fmaxf(ohz[r], ob[bb * 8 + 6]);
+            }
+        }
     }
     const float4 *X4 = reinterpret_cast<const float4 *>(lds_c);
     const float4 *Y4 = X4 + CH / 4;
     const float4 *Z4 = Y4 + CH / 4;
     const float4 *A4 = Z4 + CH / 4;
     const float4 *B4 = A4 + CH / 4;
-    const float c0 = a.c0, c1 = a.c1;
+    const float4 *BB4 = reinterpret_cast<const float4 *>(lds_bb);
+    const float c0 = a.c0, c1 = a.c1, cut2 = a.cut2;
 
     for (int q0 = 0; q0 < a.n_cand; q0 += CH) {
         const int cnt = min(CH, a.n_cand - q0);
         const int ngroups = (cnt + 3) / 4;
+        const int nblk = (cnt + kBox - 1) / kBox;
         if (q0) __syncthreads();
-        const float *src = C + (size_t)q0 * 3;
-        for (int i = tid; i < cnt * 3; i += T) {
-            const float v = src[i];
-            const int p = i / 3;
-            lds_c[(i - p * 3) * CH + p] = v;
+        // sorted SoA rows are padded to a multiple of 4 with zeros: straight float4 copies
+        {
+            float4 *dst4 = reinterpret_cast<float4 *>(lds_c);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const float4 *src4 = reinterpret_cast<const float4 *>(C + (size_t)ch * a.cand_n4 + q0);
+                for (int i = tid; i < ngroups; i += T) dst4[ch * (CH / 4) + i] = src4[i];
+            }
         }
         for (int i = tid; i < ngroups * 4; i += T) {
             const bool ok = i < cnt;
-            if (!ok) {
-                lds_c[i] = 0.f;
-                lds_c[CH + i] = 0.f;
-                lds_c[2 * CH + i] = 0.f;
-            }
             lds_c[3 * CH + i] = ok ? (W0_CONST ? a.w0c : W0[q0 + i]) : 0.f;  // padded candidates weigh 0
             if (NW == 2) lds_c[4 * CH + i] = ok ? W1[q0 + i] : 0.f;
         }
+        if (CULL) {
+            const float *cb = a.cand_box + ((size_t)smp * a.cand_nb + q0 / kBox) * 8;
+            for (int i = tid; i < nblk * 8; i += T) lds_bb[i] = cb[i];
+        }
         __syncthreads();
-        const int gs = (ngroups + S - 1) / S;
-        const int g_begin = w * gs;
-        const int g_end = min(g_begin + gs, ngroups);
-        for (int g = g_begin; g < g_end; g++) {
-            const float4 x = X4[g], y = Y4[g], z = Z4[g], wa = A4[g];
-            float4 wb;
-            if (NW == 2) wb = B4[g];
+        // blocks are dealt round-robin to the S waves: a contiguous slice of the Morton order is one compact
+        // region, so contiguous slices would make culling all-or-nothing per wave and leave the workgroup
+        // waiting for its nearest slice
+        for (int blk = w; blk < nblk; blk += S) {
+            int live[R];  // wave-uniform: does owner group r need this candidate block at all?
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                // (x2-x1)^2+(y2-y1)^2+(z2-z1)^2 with the oracle's rounding order (approxmatch.cu:54)
-                const float d0 = sq3(x.x - ox[r], y.x - oy[r], z.x - oz[r]);
-                const float d1 = sq3(x.y - ox[r], y.y - oy[r], z.y - oz[r]);
-                const float d2 = sq3(x.z - ox[r], y.z - oy[r], z.z - oz[r]);
-                const float d3 = sq3(x.w - ox[r], y.w - oy[r], z.w - oz[r]);
-                s0[r] = __builtin_fmaf(fast_exp2(c0 * d0), wa.x, s0[r]);
-                s0[r] = __builtin_fmaf(fast_exp2(c0 * d1), wa.y, s0[r]);
-                s0[r] = __builtin_fmaf(fast_exp2(c0 * d2), wa.z, s0[r]);
-                s0[r] = __builtin_fmaf(fast_exp2(c0 * d3), wa.w, s0[r]);
-                if (NW == 2) {
-                    s1[r] = __builtin_fmaf(fast_exp2(c1 * d0), wb.x, s1[r]);
-                    s1[r] = __builtin_fmaf(fast_exp2(c1 * d1), wb.y, s1[r]);
-                    s1[r] = __builtin_fmaf(fast_exp2(c1 * d2), wb.z, s1[r]);
-                    s1[r] = __builtin_fmaf(fast_exp2(c1 * d3), wb.w, s1[r]);
+            for (int r = 0; r < R; r++) live[r] = 1;
+            if (CULL) {
+                const float4 lo = BB4[2 * blk], hi = BB4[2 * blk + 1];
+                int any = 0;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float dx = fmaxf(fmaxf(olx[r] - hi.x, lo.x - ohx[r]), 0.f);
+                    const float dy = fmaxf(fmaxf(oly[r] - hi.y, lo.y - ohy[r]), 0.f);
+                    const float dz = fmaxf(fmaxf(olz[r] - hi.z, lo.z - ohz[r]), 0.f);
+                    // every pair of (owner group r, candidate block) has |d|^2 >= lb: all exponentials are exactly 0
+                    const bool keep = !(dx * dx + dy * dy + dz * dz > cut2);
+                    live[r] = __builtin_amdgcn_readfirstlane((int)keep);
+                    any |= live[r];
+                }
+                if (a.dbg && lane == 0) {
+                    atomicAdd(&a.dbg[0], R);
+                    int sk = 0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) sk += 1 - live[r];
+                    atomicAdd(&a.dbg[1], sk);
+                }
+                if (!any) continue;
+            }
+            const int g_end = min(blk * 4 + 4, ngroups);
+            for (int g = blk * 4; g < g_end; g++) {
+                const float4 x = X4[g], y = Y4[g], z = Z4[g], wa = A4[g];
+                float4 wb;
+                if (NW == 2) wb = B4[g];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (CULL && !live[r]) continue;
+                    // (x2-x1)^2+(y2-y1)^2+(z2-z1)^2 with the oracle's rounding order (approxmatch.cu:54)
+                    const float d0 = sq3(x.x - ox[r], y.x - oy[r], z.x - oz[r]);
+                    const float d1 = sq3(x.y - ox[r], y.y - oy[r], z.y - oz[r]);
+                    const float d2 = sq3(x.z - ox[r], y.z - oy[r], z.z - oz[r]);
+                    const float d3 = sq3(x.w - ox[r], y.w - oy[r], z.w - oz[r]);
+                    s0[r] = __builtin_fmaf(fast_exp2(c0 * d0), wa.x, s0[r]);
+                    s0[r] = __builtin_fmaf(fast_exp2(c0 * d1), wa.y, s0[r]);
+                    s0[r] = __builtin_fmaf(fast_exp2(c0 * d2), wa.z, s0[r]);
+                    s0[r] = __builtin_fmaf(fast_exp2(c0 * d3), wa.w, s0[r]);
+                    if (NW == 2) {
+                        s1[r] = __builtin_fmaf(fast_exp2(c1 * d0), wb.x, s1[r]);
+                        s1[r] = __builtin_fmaf(fast_exp2(c1 * d1), wb.y, s1[r]);
+                        s1[r] = __builtin_fmaf(fast_exp2(c1 * d2), wb.z, s1[r]);
+                        s1[r] = __builtin_fmaf(fast_exp2(c1 * d3), wb.w, s1[r]);
+                    }
                 }
             }
         }
@@ -202,6 +269,234 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Spatial sort: one workgroup per (sample, cloud) orders the points along a 30-bit Hilbert curve with a
+// bitonic sort of (code << 32 | index) keys in LDS and writes the sorted SoA coordinates, the inverse
+// permutation (rank) and one bounding box per 16 consecutive sorted points.  Clouds too large for the LDS
+// sort (> 16384 points) keep their original order: culling then simply finds little to skip.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned part1by2(unsigned v) {
+    v &= 0x3ff;
+    v = (v | (v << 16)) & 0x030000ff;
+    v = (v | (v << 8)) & 0x0300f00f;
+    v = (v | (v << 4)) & 0x030c30c3;
+    v = (v | (v << 2)) & 0x09249249;
+    return v;
+}
+
+// 30-bit Hilbert index of a 10-bit lattice point (Skilling's axes-to-transpose, then bit interleave).
+// Unlike the Morton order, every contiguous run of the Hilbert order is spatially compact, so all owner
+// tiles get similar, small bounding boxes (a Morton run that straddles an octant boundary spans the cloud).
+__device__ __forceinline__ unsigned hilbert3(unsigned x0, unsigned x1, unsigned x2) {
+    unsigned X[3] = {x0, x1, x2};
+    const unsigned M = 1u << 9;
+    for (unsigned Q = M; Q > 1; Q >>= 1) {
+        const unsigned P = Q - 1;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (X[i] & Q) {
+                X[0] ^= P;
+            } else {
+                const unsigned t = (X[0] ^ X[i]) & P;
+                X[0] ^= t;
+                X[i] ^= t;
+            }
+        }
+    }
+    X[1] ^= X[0];
+    X[2] ^= X[1];
+    unsigned t = 0;
+    for (unsigned Q = M; Q > 1; Q >>= 1)
+        if (X[2] & Q) t ^= Q - 1;
+    X[0] ^= t;
+    X[1] ^= t;
+    X[2] ^= t;
+    return (part1by2(X[0]) << 2) | (part1by2(X[1]) << 1) | part1by2(X[2]);
+}
+
+struct SortArgs {  // one entry per cloud; blockIdx.y selects it
+    int n[2], n4[2], nb[2], npad[2];
+    const float *xyz[2];
+    float *soa[2];
+    int *rank[2];
+    float *box[2];
+};
+
+// Bitonic sort of NPAD = kSortT*SLOTS 32-bit keys held in registers (element i = tid + kSortT*slot) by a
+// 4-wave workgroup: strides >= kSortT are in-register exchanges, strides < 64 are wave shuffles, only the
+// strides 64 and 128 go through LDS (18 cheap 4-wave barriers for 2048 keys).  Fully unrolled so that every
+// register index is static.  A key is (truncated Hilbert code << idx_bits) | point index: keys are unique and
+// one v_min_u32 / v_max_u32 pair is a whole compare-exchange.
+constexpr int kSortT = 256;
+
+template <int SLOTS>
+__device__ __forceinline__ void bitonic_sort(unsigned (&key)[SLOTS], unsigned *lds, int tid) {
+    constexpr int NPAD = kSortT * SLOTS;
+#pragma unroll
+    for (int kk = 2; kk <= NPAD; kk <<= 1) {
+#pragma unroll
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j >= kSortT) {
+                const int sj = j / kSortT;
+#pragma unroll
+                for (int s = 0; s < SLOTS; s++) {
+                    const int sp = s ^ sj;
+                    if (sp > s) {
+                        const bool asc = ((tid + kSortT * s) & kk) == 0;
+                        const unsigned mn = min(key[s], key[sp]), mx = max(key[s], key[sp]);
+                        key[s] = asc ? mn : mx;
+                        key[sp] = asc ? mx : mn;
+                    }
+                }
+            } else {
+                if (j >= 64) {
+                    __syncthreads();
+#pragma unroll
+                    for (int s = 0; s < SLOTS; s++) lds[tid + kSortT * s] = key[s];
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int s = 0; s < SLOTS; s++) {
+                    const int i = tid + kSortT * s;
+                    const unsigned other = j >= 64 ? lds[(tid ^ j) + kSortT * s] : (unsigned)__shfl_xor((int)key[s], j, 64);
+                    const bool take_min = ((i & j) == 0) == ((i & kk) == 0);
+                    key[s] = take_min ? min(key[s], other) : max(key[s], other);
+                }
+            }
+        }
+    }
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
+    __shared__ unsigned lds_keys[kSortT * SLOTS];
+    __shared__ float red[6][16];
+    const int which = blockIdx.y;
+    const int n = a.n[which], n4 = a.n4[which], nb = a.nb[which], npad = a.npad[which];
+    const int smp = blockIdx.x, tid = threadIdx.x, T = kSortT;
+    const float *p = a.xyz[which] + (size_t)smp * n * 3;
+    float *so = a.soa[which] + (size_t)smp * 3 * n4;
+    int *rk = a.rank[which] + (size_t)smp * n;
+    float *bx = a.box[which] + (size_t)smp * nb * 8;
+    int idx_bits = 10;
+    while ((1 << idx_bits) < npad) idx_bits++;  // npad >= 1024
+    const unsigned idx_mask = (1u << idx_bits) - 1;
+    if (npad) {
+        const int code_shift = 30 - 3 * ((32 - idx_bits) / 3);  // keep the leading 3*floor((32-idx_bits)/3) code bits
+        float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+        float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        for (int i = tid; i < n; i += T)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float v = p[i * 3 + c];
+                lo[c] = fminf(lo[c], v);
+                hi[c] = fmaxf(hi[c], v);
+            }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo[c] = fminf(lo[c], __shfl_down(lo[c], off, 64));
+                hi[c] = fmaxf(hi[c], __shfl_down(hi[c], off, 64));
+            }
+            if ((tid & 63) == 0) {
+                red[c][tid >> 6] = lo[c];
+                red[3 + c][tid >> 6] = hi[c];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float l = red[c][0], h = red[3 + c][0];
+            for (int i = 1; i < kSortT / 64; i++) {
+                l = fminf(l, red[c][i]);
+                h = fmaxf(h, red[3 + c][i]);
+            }
+            lo[c] = l;
+            hi[c] = h > l ? 1023.f / (h - l) : 0.f;  // scale
+        }
+        unsigned key[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) {
+            const int i = tid + kSortT * s;
+            key[s] = ~0u;
+            if (i < n) {
+                const unsigned qx = (unsigned)fminf(fmaxf((p[i * 3 + 0] - lo[0]) * hi[0], 0.f), 1023.f);
+                const unsigned qy = (unsigned)fminf(fmaxf((p[i * 3 + 1] - lo[1]) * hi[1], 0.f), 1023.f);
+                const unsigned qz = (unsigned)fminf(fmaxf((p[i * 3 + 2] - lo[2]) * hi[2], 0.f), 1023.f);
+                key[s] = ((hilbert3(qx, qy, qz) >> code_shift) << idx_bits) | (unsigned)i;
+            }
+        }
+        bitonic_sort<SLOTS>(key, lds_keys, tid);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SLOTS; s++) lds_keys[tid + kSortT * s] = key[s];
+        __syncthreads();
+    }
+    // sorted SoA rows + inverse permutation; the box of every 16 consecutive sorted points falls out of a
+    // 16-lane min/max butterfly on the coordinates the lanes already hold
+    const int span = ((max(n4, nb * kBox) + 63) / 64) * 64;
+    for (int s = tid; s < span; s += T) {
+        float x = 0.f, y = 0.f, z = 0.f;
+        const bool real = s < n;
+        if (real) {
+            const int orig = npad ? (int)(lds_keys[s] & idx_mask) : s;
+            x = p[orig * 3 + 0];
+            y = p[orig * 3 + 1];
+            z = p[orig * 3 + 2];
+            rk[orig] = s;
+        }
+        if (s < n4) {
+            so[s] = x;
+            so[n4 + s] = y;
+            so[2 * n4 + s] = z;
+        }
+        float l0 = real ? x : __builtin_inff(), l1 = real ? y : __builtin_inff(), l2 = real ? z : __builtin_inff();
+        float h0 = real ? x : -__builtin_inff(), h1 = real ? y : -__builtin_inff(), h2 = real ? z : -__builtin_inff();
+#pragma unroll
+        for (int off = 1; off < kBox; off <<= 1) {
+            l0 = fminf(l0, __shfl_xor(l0, off, 64));
+            l1 = fminf(l1, __shfl_xor(l1, off, 64));
+            l2 = fminf(l2, __shfl_xor(l2, off, 64));
+            h0 = fmaxf(h0, __shfl_xor(h0, off, 64));
+            h1 = fmaxf(h1, __shfl_xor(h1, off, 64));
+            h2 = fmaxf(h2, __shfl_xor(h2, off, 64));
+        }
+        const int bb = s / kBox;
+        if ((s & (kBox - 1)) == 0 && bb < nb) {
+            float4 *dst = reinterpret_cast<float4 *>(bx + (size_t)bb * 8);
+            dst[0] = make_float4(l0, l1, l2, 0.f);
+            dst[1] = make_float4(h0, h1, h2, 0.f);
+        }
+    }
+}
+
+// The phases run in Hilbert-sorted index space; this puts the nine (ratioL | ratioR) level vectors back into
+// the caller's point order for the materialise pass (contiguous loads there) and fills
+// temp = remainL | remainR | ratioL | ratioR of the last level (approxmatch.cu:4).
+__global__ __launch_bounds__(256) void am_unpermute_kernel(int n, int m, const float *__restrict__ lv_sorted,
+                                                            const float *__restrict__ rem_sorted,
+                                                            const int *__restrict__ rank1,
+                                                            const int *__restrict__ rank2,
+                                                            float *__restrict__ lv, float *__restrict__ temp) {
+    const int smp = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n + m) return;
+    const int s = i < n ? rank1[(size_t)smp * n + i] : n + rank2[(size_t)smp * m + (i - n)];
+    const size_t nm = (size_t)n + m;
+    const float *src = lv_sorted + (size_t)smp * kLevels * nm;
+    float *dst = lv + (size_t)smp * kLevels * nm;
+    float last = 0.f;
+#pragma unroll
+    for (int l = 0; l < kLevels; l++) {
+        last = src[(size_t)l * nm + s];
+        dst[(size_t)l * nm + i] = last;
+    }
+    float *tb = temp + (size_t)smp * 2 * nm;
+    tb[i] = rem_sorted[(size_t)smp * nm + s];
+    tb[nm + i] = last;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Materialise: match[b,l,k] = sum_i (exp2(c_i d2) * ratioL_i[k]) * ratioR_i[l], i = 0..8 in the
 // reference's accumulation order (approxmatch.cu:154-155).  Write-only on match (float4 rows).
 // Optionally also accumulates cost partials sum match*sqrt(d2) (matchcost, :207-208) so that the
@@ -214,7 +509,7 @@ template <bool COST, bool VEC>
 __global__ __launch_bounds__(256) void am_materialise_kernel(int n, int m, const float *__restrict__ xyz1,
                                                               const float *__restrict__ xyz2,
                                                               const float *__restrict__ lv, LevelConsts lc,
-                                                              float *__restrict__ match, float *__restrict__ temp,
+                                                              float *__restrict__ match,
                                                               float *__restrict__ cost_part) {
     __shared__ float4 lds_l[kMatLT][3];  // (x,y,z,rr0) (rr1..rr4) (rr5..rr8)
     __shared__ float lds_red[4];
@@ -237,14 +532,6 @@ __global__ __launch_bounds__(256) void am_materialise_kernel(int n, int m, const
         lds_l[tid][0] = make_float4(p2[l * 3 + 0], p2[l * 3 + 1], p2[l * 3 + 2], rr[0]);
         lds_l[tid][1] = make_float4(rr[1], rr[2], rr[3], rr[4]);
         lds_l[tid][2] = make_float4(rr[5], rr[6], rr[7], rr[8]);
-    }
-    // The first tile of each sample also publishes the last level's ratios into temp
-    // (temp = remainL | remainR | ratioL | ratioR, approxmatch.cu:4).
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        float *tb = temp + (size_t)smp * 2 * (n + m);
-        const float *last = lvb + (size_t)(kLevels - 1) * (n + m);
-        for (int i = tid; i < n; i += 256) tb[n + m + i] = last[i];
-        for (int i = tid; i < m; i += 256) tb[n + m + n + i] = last[n + i];
     }
     float x1[4], y1[4], z1[4], rl[kLevels][4];
 #pragma unroll
@@ -511,22 +798,44 @@ static int phase_cfg_override() {
     }();
     return v;
 }
+static bool cull_enabled() {
+    static const bool v = [] {
+        const char *e = std::getenv("PCC_AM_NOCULL");
+        return !(e && e[0] == '1');
+    }();
+    return v;
+}
+
+template <int MODE>
+const char *phase_name(int level) {
+    static const char *const names[4][kLevels] = {
+        {"am_phase_kernel<A> L0", "", "", "", "", "", "", "", ""},
+        {"am_phase_kernel<B> L0", "am_phase_kernel<B> L1", "am_phase_kernel<B> L2", "am_phase_kernel<B> L3",
+         "am_phase_kernel<B> L4", "am_phase_kernel<B> L5", "am_phase_kernel<B> L6", "am_phase_kernel<B> L7",
+         "am_phase_kernel<B> L8"},
+        {"am_phase_kernel<CA> L0", "am_phase_kernel<CA> L1", "am_phase_kernel<CA> L2", "am_phase_kernel<CA> L3",
+         "am_phase_kernel<CA> L4", "am_phase_kernel<CA> L5", "am_phase_kernel<CA> L6", "am_phase_kernel<CA> L7", ""},
+        {"", "", "", "", "", "", "", "", "am_phase_kernel<C> L8"}};
+    return names[MODE][level];
+}
 
 template <int MODE, int R, int S>
-int launch_phase_rs(PhaseArgs a, int b, hipStream_t st, const char *what) {
+int launch_phase_rs(PhaseArgs a, int b, bool cull, hipStream_t st, const char *what) {
     a.tiles = pcc::ceil_div(a.n_own, 64 * R);
     const long long grid = (long long)b * a.tiles;
     if (grid > 0x7fffffffLL) return pcc::invalid("approxmatch: grid too large");
     {
-        pcc::ProfScope prof(MODE == PH_CA ? "am_phase_kernel<CA>" : MODE == PH_B ? "am_phase_kernel<B>"
-                            : MODE == PH_A ? "am_phase_kernel<A>" : "am_phase_kernel<C>", st);
-        hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH>), dim3((unsigned)grid), dim3(64 * S), 0, st, a);
+        pcc::ProfScope prof(phase_name<MODE>(a.level), st);
+        if (cull)
+            hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, true>), dim3((unsigned)grid), dim3(64 * S), 0, st, a);
+        else
+            hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, false>), dim3((unsigned)grid), dim3(64 * S), 0, st, a);
     }
     return pcc::check_launch(what);
 }
 
 template <int MODE>
-int launch_phase(const PhaseArgs &a, int b, hipStream_t st, const char *what) {
+int launch_phase(const PhaseArgs &a, int b, bool cull, hipStream_t st, const char *what) {
     int cfg = phase_cfg_override();
     if (cfg == 0) {
         const long long owners = (long long)b * a.n_own;
@@ -537,13 +846,12 @@ int launch_phase(const PhaseArgs &a, int b, hipStream_t st, const char *what) {
         else cfg = 18;
     }
     switch (cfg) {
-    case 44: return launch_phase_rs<MODE, 4, 4>(a, b, st, what);
-    case 48: return launch_phase_rs<MODE, 4, 8>(a, b, st, what);
-    case 24: return launch_phase_rs<MODE, 2, 4>(a, b, st, what);
-    case 28: return launch_phase_rs<MODE, 2, 8>(a, b, st, what);
-    case 14: return launch_phase_rs<MODE, 1, 4>(a, b, st, what);
-    case 216: return launch_phase_rs<MODE, 2, 16>(a, b, st, what);
-    default: return launch_phase_rs<MODE, 1, 8>(a, b, st, what);
+    case 44: return launch_phase_rs<MODE, 4, 4>(a, b, cull, st, what);
+    case 48: return launch_phase_rs<MODE, 4, 8>(a, b, cull, st, what);
+    case 28: return launch_phase_rs<MODE, 2, 8>(a, b, cull, st, what);
+    case 216: return launch_phase_rs<MODE, 2, 16>(a, b, cull, st, what);
+    case 116: return launch_phase_rs<MODE, 1, 16>(a, b, cull, st, what);
+    default: return launch_phase_rs<MODE, 1, 8>(a, b, cull, st, what);
     }
 }
 
@@ -578,65 +886,168 @@ struct StreamBuf {  // stream-ordered scratch (hipMallocAsync / hipFreeAsync)
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-size_t levels_bytes(int b, int n, int m) { return (size_t)b * kLevels * ((size_t)n + m) * sizeof(float); }
 size_t cost_parts(int n, int m) { return (size_t)pcc::ceil_div(n, kMatKT) * pcc::ceil_div(m, kMatLT); }
+
+// Workspace carve (bytes, every section 16-byte aligned).
+struct WsLayout {
+    int n4, m4, nb1, nb2;
+    size_t soa1, soa2, rank1, rank2, box1, box2, rem, lv, lv_orig, cpart, total;
+    WsLayout(int b, int n, int m) {
+        auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        n4 = (n + 3) & ~3;
+        m4 = (m + 3) & ~3;
+        nb1 = pcc::ceil_div(n, kBox);
+        nb2 = pcc::ceil_div(m, kBox);
+        size_t o = 0;
+        soa1 = o; o = up(o + (size_t)b * 3 * n4 * 4);
+        soa2 = o; o = up(o + (size_t)b * 3 * m4 * 4);
+        rank1 = o; o = up(o + (size_t)b * n * 4);
+        rank2 = o; o = up(o + (size_t)b * m * 4);
+        box1 = o; o = up(o + (size_t)b * nb1 * 8 * 4);
+        box2 = o; o = up(o + (size_t)b * nb2 * 8 * 4);
+        rem = o; o = up(o + (size_t)b * ((size_t)n + m) * 4);
+        lv = o; o = up(o + (size_t)b * kLevels * ((size_t)n + m) * 4);
+        lv_orig = o; o = up(o + (size_t)b * kLevels * ((size_t)n + m) * 4);
+        cpart = o; o = up(o + (size_t)b * cost_parts(n, m) * 4);
+        total = o;
+    }
+};
+
+int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const float *xyz2, float *soa1, float *soa2,
+                int *rank1, int *rank2, float *box1, float *box2, hipStream_t st) {
+    SortArgs a{};
+    const int nn[2] = {n, m};
+    int slots = 4;
+    for (int w = 0; w < 2; w++) {
+        int npad = 4 * kSortT;
+        while (npad < nn[w]) npad <<= 1;
+        if (npad > 64 * kSortT) npad = 0;  // > 16384 points: keep the original order (nothing is culled)
+        a.n[w] = nn[w];
+        a.npad[w] = npad;
+        slots = std::max(slots, npad / kSortT);
+    }
+    for (int w = 0; w < 2; w++)
+        if (a.npad[w]) a.npad[w] = kSortT * slots;  // one SLOTS instantiation serves both clouds
+    a.n4[0] = L.n4; a.n4[1] = L.m4; a.nb[0] = L.nb1; a.nb[1] = L.nb2;
+    a.xyz[0] = xyz1; a.xyz[1] = xyz2; a.soa[0] = soa1; a.soa[1] = soa2;
+    a.rank[0] = rank1; a.rank[1] = rank2; a.box[0] = box1; a.box[1] = box2;
+    pcc::ProfScope prof("am_sort_kernel", st);
+    const dim3 grid(b, 2);
+    switch (slots) {
+    case 4: hipLaunchKernelGGL((am_sort_kernel<4>), grid, dim3(kSortT), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((am_sort_kernel<8>), grid, dim3(kSortT), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((am_sort_kernel<16>), grid, dim3(kSortT), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((am_sort_kernel<32>), grid, dim3(kSortT), 0, st, a); break;
+    default: hipLaunchKernelGGL((am_sort_kernel<64>), grid, dim3(kSortT), 0, st, a); break;
+    }
+    return pcc::check_launch("approxmatch(sort)");
+}
 
 int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
                      void *workspace, size_t workspace_bytes, float *cost_out, hipStream_t st) {
-    const size_t need = levels_bytes(b, n, m) + (cost_out ? (size_t)b * cost_parts(n, m) * sizeof(float) : 0);
-    if (workspace_bytes < need) return pcc::invalid("approxmatch: workspace too small");
-    float *lv = static_cast<float *>(workspace);
-    float *cpart = lv + (size_t)b * kLevels * ((size_t)n + m);
+    const WsLayout L(b, n, m);
+    if (workspace_bytes < L.total) return pcc::invalid("approxmatch: workspace too small");
+    if (!aligned16(workspace)) return pcc::invalid("approxmatch: workspace must be 16-byte aligned");
+    char *base = static_cast<char *>(workspace);
+    float *soa1 = reinterpret_cast<float *>(base + L.soa1), *soa2 = reinterpret_cast<float *>(base + L.soa2);
+    int *rank1 = reinterpret_cast<int *>(base + L.rank1), *rank2 = reinterpret_cast<int *>(base + L.rank2);
+    float *box1 = reinterpret_cast<float *>(base + L.box1), *box2 = reinterpret_cast<float *>(base + L.box2);
+    float *rem = reinterpret_cast<float *>(base + L.rem);
+    float *lv = reinterpret_cast<float *>(base + L.lv);
+    float *lv_orig = reinterpret_cast<float *>(base + L.lv_orig);
+    float *cpart = reinterpret_cast<float *>(base + L.cpart);
     const LevelConsts lc = make_levels();
     float multiL, multiR;  // approxmatch.cu:6-12 (integer division)
     if (n >= m) { multiL = 1; multiR = (float)(n / m); }
     else { multiL = (float)(m / n); multiR = 1; }
     const long long nm = (long long)n + m;
 
+    int rc = sort_clouds(b, L, n, m, xyz1, xyz2, soa1, soa2, rank1, rank2, box1, box2, st);
+    if (rc) return rc;
+
+    // A level is worth culling while its zero radius is small against the cloud; beyond level 3 (|c| < 92,
+    // radius > 1.2) nothing can be skipped for unit-ball clouds and the box test would be pure overhead.
+    static const float cut_scale = [] {  // debugging aid: PCC_AM_CUTSCALE < 1 skips more than is exact
+        const char *e = std::getenv("PCC_AM_CUTSCALE");
+        return e ? (float)std::atof(e) : 1.0f;
+    }();
+    auto cut_of = [&](int i) { return cut_scale * kZeroExp / -lc.c[i]; };
+    auto cull_at = [&](int i) { return cull_enabled() && i <= 3; };
+
+    auto owner1 = [&](PhaseArgs &a) {  // owners = set1, candidates = set2
+        a.n_own = n; a.n_cand = m; a.own_n4 = L.n4; a.cand_n4 = L.m4; a.own_nb = L.nb1; a.cand_nb = L.nb2;
+        a.own_soa = soa1; a.cand_soa = soa2; a.own_box = box1; a.cand_box = box2;
+    };
+    auto owner2 = [&](PhaseArgs &a) {  // owners = set2, candidates = set1
+        a.n_own = m; a.n_cand = n; a.own_n4 = L.m4; a.cand_n4 = L.n4; a.own_nb = L.nb2; a.cand_nb = L.nb1;
+        a.own_soa = soa2; a.cand_soa = soa1; a.own_box = box2; a.cand_box = box1;
+    };
+
+    static int *dbg_counters = [] {
+        int *p = nullptr;
+        const char *e = std::getenv("PCC_AM_DEBUG");
+        if (e && e[0] == '1' && hipMalloc(reinterpret_cast<void **>(&p), 64 * sizeof(int)) == hipSuccess)
+            (void)hipMemset(p, 0, 64 * sizeof(int));
+        return p;
+    }();
     PhaseArgs a{};
+    a.dbg = dbg_counters;
     a.multiL = multiL; a.multiR = multiR;
-    // pass A of the first level
-    a.n_own = n; a.n_cand = m;
-    a.own_xyz = xyz1; a.cand_xyz = xyz2;
-    a.w0 = nullptr; a.w0c = multiR; a.c0 = lc.c[0]; a.first = 1;
+    owner1(a);
+    a.w0 = nullptr; a.w0c = multiR; a.c0 = lc.c[0]; a.first = 1; a.cut2 = cut_of(0);
     a.ratio_out = lv; a.ratio_stride = kLevels * nm;
-    int rc = launch_phase<PH_A>(a, b, st, "approxmatch(A)");
+    rc = launch_phase<PH_A>(a, b, cull_at(0), st, "approxmatch(A)");
     if (rc) return rc;
     for (int i = 0; i < kLevels; i++) {
         float *ratioL = lv + (size_t)i * nm, *ratioR = ratioL + n;
         PhaseArgs pb{};
-        pb.multiL = multiL; pb.multiR = multiR; pb.first = (i == 0);
-        pb.n_own = m; pb.n_cand = n;
-        pb.own_xyz = xyz2; pb.cand_xyz = xyz1;
-        pb.w0 = ratioL; pb.w0_stride = kLevels * nm; pb.c0 = lc.c[i];
-        pb.remain = temp + n; pb.remain_stride = 2 * nm;
+        pb.dbg = dbg_counters ? dbg_counters + 2 + 4 * i : nullptr;
+        pb.multiL = multiL; pb.multiR = multiR; pb.first = (i == 0); pb.level = i;
+        owner2(pb);
+        pb.w0 = ratioL; pb.w0_stride = kLevels * nm; pb.c0 = lc.c[i]; pb.cut2 = cut_of(i);
+        pb.remain = rem + n; pb.remain_stride = nm;
         pb.ratio_out = ratioR; pb.ratio_stride = kLevels * nm;
-        rc = launch_phase<PH_B>(pb, b, st, "approxmatch(B)");
+        rc = launch_phase<PH_B>(pb, b, cull_at(i), st, "approxmatch(B)");
         if (rc) return rc;
         PhaseArgs pc{};
-        pc.multiL = multiL; pc.multiR = multiR; pc.first = (i == 0);
-        pc.n_own = n; pc.n_cand = m;
-        pc.own_xyz = xyz1; pc.cand_xyz = xyz2;
+        pc.dbg = dbg_counters ? dbg_counters + 4 + 4 * i : nullptr;
+        pc.multiL = multiL; pc.multiR = multiR; pc.first = (i == 0); pc.level = i;
+        owner1(pc);
         pc.w0 = ratioR; pc.w0_stride = kLevels * nm; pc.c0 = lc.c[i];
-        pc.w1 = temp + n; pc.w1_stride = 2 * nm;
-        pc.remain = temp; pc.remain_stride = 2 * nm;
+        pc.w1 = rem + n; pc.w1_stride = nm;
+        pc.remain = rem; pc.remain_stride = nm;
         pc.ratio_in = ratioL; pc.ratio_stride = kLevels * nm;
         if (i + 1 < kLevels) {
             pc.c1 = lc.c[i + 1];
+            pc.cut2 = cut_of(i + 1);  // the coarser of the two levels decides what is exactly zero
             pc.ratio_out = lv + (size_t)(i + 1) * nm;
-            rc = launch_phase<PH_CA>(pc, b, st, "approxmatch(CA)");
+            rc = launch_phase<PH_CA>(pc, b, cull_at(i + 1), st, "approxmatch(CA)");
         } else {
-            rc = launch_phase<PH_C>(pc, b, st, "approxmatch(C)");
+            pc.cut2 = cut_of(i);
+            rc = launch_phase<PH_C>(pc, b, cull_at(i), st, "approxmatch(C)");
         }
         if (rc) return rc;
     }
+    if (dbg_counters) {
+        int h[64];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, dbg_counters, sizeof h, hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[pcc dbg] A: %d/%d skipped;", h[1], h[0]);
+        for (int i = 0; i < 4; i++) std::fprintf(stderr, " B%d %d/%d CA%d %d/%d;", i, h[3 + 4 * i], h[2 + 4 * i], i, h[5 + 4 * i], h[4 + 4 * i]);
+        std::fprintf(stderr, "\n");
+        (void)hipMemset(dbg_counters, 0, sizeof h);
+    }
+    hipLaunchKernelGGL(am_unpermute_kernel, dim3(pcc::ceil_div(n + m, 256), b), dim3(256), 0, st, n, m, lv, rem, rank1, rank2,
+                       lv_orig, temp);
+    rc = pcc::check_launch("approxmatch(unpermute)");
+    if (rc) return rc;
     const dim3 grid(pcc::ceil_div(n, kMatKT), pcc::ceil_div(m, kMatLT), b);
     const bool vec = (n % 4 == 0) && aligned16(match);
     if (cost_out) {
         {
             pcc::ProfScope prof("am_materialise_kernel<cost>", st);
-            if (vec) hipLaunchKernelGGL((am_materialise_kernel<true, true>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, cpart);
-            else hipLaunchKernelGGL((am_materialise_kernel<true, false>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, cpart);
+            if (vec) hipLaunchKernelGGL((am_materialise_kernel<true, true>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv_orig, lc, match, cpart);
+            else hipLaunchKernelGGL((am_materialise_kernel<true, false>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv_orig, lc, match, cpart);
         }
         rc = pcc::check_launch("approxmatch(materialise+cost)");
         if (rc) return rc;
@@ -645,8 +1056,8 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
     }
     {
         pcc::ProfScope prof("am_materialise_kernel", st);
-        if (vec) hipLaunchKernelGGL((am_materialise_kernel<false, true>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, nullptr);
-        else hipLaunchKernelGGL((am_materialise_kernel<false, false>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv, lc, match, temp, nullptr);
+        if (vec) hipLaunchKernelGGL((am_materialise_kernel<false, true>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv_orig, lc, match, nullptr);
+        else hipLaunchKernelGGL((am_materialise_kernel<false, false>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv_orig, lc, match, nullptr);
     }
     return pcc::check_launch("approxmatch(materialise)");
 }
@@ -663,7 +1074,7 @@ extern "C" {
 
 size_t pcc_approxmatch_workspace_bytes(int b, int n, int m) {
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    return levels_bytes(b, n, m) + (size_t)b * cost_parts(n, m) * sizeof(float);
+    return WsLayout(b, n, m).total;
 }
 
 int pcc_approxmatch_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
@@ -684,7 +1095,7 @@ int pcc_approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, f
     if (!xyz1 || !xyz2 || !match || !temp) return pcc::invalid("approxmatch: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     StreamBuf ws(st);
-    const size_t bytes = levels_bytes(b, n, m);
+    const size_t bytes = WsLayout(b, n, m).total;
     if (int rc = ws.alloc(bytes)) return rc;
     return approxmatch_impl(b, n, m, xyz1, xyz2, match, temp, ws.p, bytes, nullptr, st);
 }

@@ -50,7 +50,7 @@ def test_workspace_query_is_host_only():
 
     assert _lib.lib.pcc_approxmatch_workspace_bytes(0, 10, 10) == 0
     nbytes = _lib.lib.pcc_approxmatch_workspace_bytes(32, 2048, 2048)
-    assert nbytes >= 32 * 9 * 4096 * 4
+    assert nbytes >= 32 * 9 * 4096 * 4  # at least the nine per-level ratio vectors
 
 
 def test_backend_rejects_cpu_and_non_contiguous_like_the_reference():
