@@ -772,6 +772,146 @@ __global__ __launch_bounds__(256) void am_col_kernel(int n, int m, int rs, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// matchcostgrad, fused: ONE read of match produces both gradients (the reference reads it twice,
+// approxmatch.cu:319-320).  A workgroup takes RT rows (points k of set2) x a 2048-column slab (points l of set1);
+// a wave streams whole row segments with float4 loads; per element t = d * match * rsqrt(max(|d|^2,1e-20)):
+//   grad1[l] += t   (column sums: 4 columns x 3 components per lane per 256-column step, kept in registers,
+//                    merged over the 4 waves in LDS, written as one partial per row tile)
+//   grad2[k] -= t   (row sums: per-lane partials, wave butterfly at the end of the row segment)
+// Partials are combined in a fixed order by reduce_splits_kernel / the slab loop: deterministic.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kGradRT = 64;     // rows per workgroup (16 per wave)
+constexpr int kGradSlab = 2048;  // columns per slab = 8 steps of 256
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void am_grad_fused_kernel(int n, int m, int row_tiles,
+                                                             const float *__restrict__ xyz1,
+                                                             const float *__restrict__ xyz2,
+                                                             const float *__restrict__ match,
+                                                             float *__restrict__ part1,  // [b][row_tiles][n][3]
+                                                             float *__restrict__ part2)  // [b][slabs][m][3]
+{
+    constexpr int STEPS = kGradSlab / 256;
+    // set1 slab SoA (24 KiB); after the row loop the same bytes carry one wave's column sums at a time to wave 0
+    __shared__ __attribute__((aligned(16))) float lds_p[3 * kGradSlab > STEPS * 12 * 64 ? 3 * kGradSlab : STEPS * 12 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int smp = blockIdx.z, slab = blockIdx.y, rt = blockIdx.x;
+    const int c0 = slab * kGradSlab;
+    const int cnt = min(kGradSlab, n - c0);
+    const float *p1 = xyz1 + ((size_t)smp * n + c0) * 3;
+    const float *p2 = xyz2 + (size_t)smp * m * 3;
+    for (int i = tid; i < cnt * 3; i += 256) {
+        const float v = p1[i];
+        const int p = i / 3;
+        lds_p[(i - p * 3) * kGradSlab + p] = v;
+    }
+    for (int i = cnt + tid; i < kGradSlab; i += 256) lds_p[i] = lds_p[kGradSlab + i] = lds_p[2 * kGradSlab + i] = 0.f;
+    __syncthreads();
+    const float4 *X4 = reinterpret_cast<const float4 *>(lds_p);
+    const float4 *Y4 = X4 + kGradSlab / 4;
+    const float4 *Z4 = Y4 + kGradSlab / 4;
+
+    float g1[STEPS][4][3];
+#pragma unroll
+    for (int st = 0; st < STEPS; st++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) g1[st][q][0] = g1[st][q][1] = g1[st][q][2] = 0.f;
+
+    const int r_begin = rt * kGradRT, r_end = min(r_begin + kGradRT, m);
+    const bool full = VEC && cnt == kGradSlab;  // whole slab, aligned: branch-free body, 8 row loads in flight
+    for (int row = r_begin + w; row < r_end; row += 4) {
+        const float x2 = p2[row * 3 + 0], y2 = p2[row * 3 + 1], z2 = p2[row * 3 + 2];
+        const float *mrow = match + ((size_t)smp * m + row) * n + c0;
+        float rx = 0.f, ry = 0.f, rz = 0.f;
+        float mv[STEPS][4];
+        if (full) {
+#pragma unroll
+            for (int st = 0; st < STEPS; st++) {
+                const float4 t = *reinterpret_cast<const float4 *>(mrow + st * 256 + lane * 4);
+                mv[st][0] = t.x; mv[st][1] = t.y; mv[st][2] = t.z; mv[st][3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int st = 0; st < STEPS; st++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int k = st * 256 + lane * 4 + q;
+                    mv[st][q] = k < cnt ? mrow[k] : 0.f;  // columns past the slab contribute exactly 0
+                }
+        }
+#pragma unroll
+        for (int st = 0; st < STEPS; st++) {
+            const int k = st * 256 + lane * 4;
+            const float4 xs = X4[k >> 2], ys = Y4[k >> 2], zs = Z4[k >> 2];
+            const float px[4] = {xs.x, xs.y, xs.z, xs.w};
+            const float py[4] = {ys.x, ys.y, ys.z, ys.w};
+            const float pz[4] = {zs.x, zs.y, zs.z, zs.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                // grad1 uses (p1 - p2) (approxmatch.cu:281-284); grad2 the negated vector (:240-246)
+                const float dx = px[q] - x2, dy = py[q] - y2, dz = pz[q] - z2;
+                const float f = mv[st][q] * __builtin_amdgcn_rsqf(__builtin_fmaxf(sq3(dx, dy, dz), 1e-20f));
+                const float tx = dx * f, ty = dy * f, tz = dz * f;
+                g1[st][q][0] += tx;
+                g1[st][q][1] += ty;
+                g1[st][q][2] += tz;
+                rx -= tx;
+                ry -= ty;
+                rz -= tz;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            rx += __shfl_down(rx, off, 64);
+            ry += __shfl_down(ry, off, 64);
+            rz += __shfl_down(rz, off, 64);
+        }
+        if (lane == 0) {
+            float *dst = part2 + (((size_t)smp * gridDim.y + slab) * m + row) * 3;
+            dst[0] = rx;
+            dst[1] = ry;
+            dst[2] = rz;
+        }
+    }
+    // column partials: waves 1, 2, 3 hand their sums to wave 0 one after the other (fixed order)
+    float *red = lds_p;
+    for (int src = 1; src < 4; src++) {
+        __syncthreads();
+        if (w == src) {
+#pragma unroll
+            for (int st = 0; st < STEPS; st++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) red[((st * 4 + q) * 3 + c) * 64 + lane] = g1[st][q][c];
+        }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int st = 0; st < STEPS; st++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) g1[st][q][c] += red[((st * 4 + q) * 3 + c) * 64 + lane];
+        }
+    }
+    if (w == 0) {
+        float *dst = part1 + (((size_t)smp * row_tiles + rt) * n + c0) * 3;
+#pragma unroll
+        for (int st = 0; st < STEPS; st++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int k = st * 256 + lane * 4 + q;
+                if (k < cnt) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) dst[(size_t)k * 3 + c] = g1[st][q][c];
+                }
+            }
+    }
+}
+
 // grad1[b][i] = sum_s part[b][s][i]  (i over n*3), fixed order.
 __global__ __launch_bounds__(256) void reduce_splits_kernel(int rs, size_t per_sample, const float *__restrict__ part,
                                                              float *__restrict__ out) {
@@ -1169,29 +1309,23 @@ int pcc_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2,
     }
     if (!xyz1 || !xyz2 || !match || !grad1 || !grad2) return pcc::invalid("matchcostgrad: null pointer");
     const bool vec = (n % 4 == 0) && aligned16(match);
-    // grad2: row kernel
-    const int tiles = pcc::ceil_div(m, kRowRT);
-    {
-        pcc::ProfScope prof("am_row_kernel<grad2>", st);
-        if (vec) hipLaunchKernelGGL((am_row_kernel<1, true, 2048>), dim3(tiles, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
-        else hipLaunchKernelGGL((am_row_kernel<1, false, 2048>), dim3(tiles, b), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
-    }
-    if (int rc = pcc::check_launch("matchcostgrad(grad2)")) return rc;
-    // grad1: column kernel with RS row splits, then ordered sum of the partials
-    const int ctiles = pcc::ceil_div(n, 256);
-    int rs = pcc::ceil_div(2048, ctiles * b);
-    rs = std::max(1, std::min(rs, std::min(64, pcc::ceil_div(m, 16))));
+    const int row_tiles = pcc::ceil_div(m, kGradRT), slabs = pcc::ceil_div(n, kGradSlab);
     StreamBuf ws(st);
-    if (int rc = ws.alloc((size_t)b * rs * n * 3 * sizeof(float))) return rc;
-    float *part = static_cast<float *>(ws.p);
+    const size_t p1_elems = (size_t)b * row_tiles * n * 3, p2_elems = slabs > 1 ? (size_t)b * slabs * m * 3 : 0;
+    if (int rc = ws.alloc((p1_elems + p2_elems) * sizeof(float))) return rc;
+    float *part1 = static_cast<float *>(ws.p);
+    float *part2 = slabs > 1 ? part1 + p1_elems : grad2;  // a single slab writes grad2 directly
     {
-        pcc::ProfScope prof("am_col_kernel<grad1>", st);
-        if (vec) hipLaunchKernelGGL((am_col_kernel<true>), dim3(ctiles, rs, b), dim3(256), 0, st, n, m, rs, xyz1, xyz2, match, part);
-        else hipLaunchKernelGGL((am_col_kernel<false>), dim3(ctiles, rs, b), dim3(256), 0, st, n, m, rs, xyz1, xyz2, match, part);
+        pcc::ProfScope prof("am_grad_fused_kernel", st);
+        const dim3 grid(row_tiles, slabs, b);
+        if (vec) hipLaunchKernelGGL((am_grad_fused_kernel<true>), grid, dim3(256), 0, st, n, m, row_tiles, xyz1, xyz2, match, part1, part2);
+        else hipLaunchKernelGGL((am_grad_fused_kernel<false>), grid, dim3(256), 0, st, n, m, row_tiles, xyz1, xyz2, match, part1, part2);
     }
-    if (int rc = pcc::check_launch("matchcostgrad(grad1)")) return rc;
-    const size_t per = (size_t)n * 3;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((per + 255) / 256), b), dim3(256), 0, st, rs, per, part, grad1);
+    if (int rc = pcc::check_launch("matchcostgrad(fused)")) return rc;
+    const size_t per1 = (size_t)n * 3, per2 = (size_t)m * 3;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((per1 + 255) / 256), b), dim3(256), 0, st, row_tiles, per1, part1, grad1);
+    if (slabs > 1)
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((per2 + 255) / 256), b), dim3(256), 0, st, slabs, per2, part2, grad2);
     return pcc::check_launch("matchcostgrad(reduce)");
 }
 
