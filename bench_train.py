@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""End-to-end harness benchmarks for BASELINE configs[3] and configs[4].
+
+  python bench_train.py --mode train --gpus N --steps K --warmup W   autoencoder training step, B=32 per GPU
+  python bench_train.py --mode infer --gpus N ...                    encoder -> classifier -> decoder + Chamfer/EMD metric
+
+N>1: launch with ``python -m torch.distributed.run --nproc-per-node N ... bench_train.py --gpus N``; one rank per
+GPU, gradients averaged by DDP over RCCL (training) / no collective at all (inference).  Prints one JSON line on
+rank 0 in the bench.py format.  The headline metric of the repository stays bench.py; this file measures the rows
+SURVEY.md marks "next".
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--mode', choices=['train', 'infer'], default='train')
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch-per-gpu', type=int, default=32)
+    ap.add_argument('--points', type=int, default=2048)
+    args = ap.parse_args()
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from pointcloudcounterfactual_amd import harness
+    from pointcloudcounterfactual_amd.losses import chamfer, match_cost
+    from tests.util import pair
+
+    torch.manual_seed(1234 + 4 + rank)
+    _, ref = pair(1234 + 4 + 1000 * rank, args.batch_per_gpu, args.points, args.points, 'recon')
+    ref_t = torch.from_numpy(ref).to(dev)
+    model = harness.VQAutoencoder(n_points=args.points).to(dev)
+    clf = harness.DGCNNClassifier().to(dev)
+    if args.mode == 'train':
+        model.train()
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if dist is not None else model
+        opt = harness.make_optimizer(model)
+
+        def step() -> None:
+            opt.zero_grad(set_to_none=True)
+            out = net(ref_t)
+            harness.autoencoder_loss(out, ref_t).mean().backward()
+            opt.step()
+    else:
+        model.eval()
+        clf.eval()
+
+        @torch.inference_mode()
+        def step() -> None:
+            logits = clf(ref_t)
+            out = model(ref_t)
+            _metric = chamfer(out['recon'], ref_t) + match_cost(out['recon'], ref_t)
+            _pred = clf(out['recon']).argmax(1) == logits.argmax(1)
+
+    def sync() -> None:
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'clouds/sec ' + ('autoencoder train step (DGCNN enc + PCGen dec + Chamfer + EMD + AdamW)'
+                                       if args.mode == 'train' else
+                                       'inference pipeline (classifier + encoder + decoder + Chamfer/EMD metric)'),
+            'value': args.batch_per_gpu * world * args.steps / el, 'unit': 'clouds/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[{3 if args.mode == "train" else 4}] harness, N={args.points}, '
+                                   f'B={args.batch_per_gpu} per GPU, random-init weights',
+                       'global_batch': args.batch_per_gpu * world,
+                       'parallelism': f'dp{world}' + (' (DDP all-reduce over RCCL)' if args.mode == 'train' else ' (no collective)')},
+            'peak_mem_gib': torch.cuda.max_memory_allocated() / 2**30,
+        }), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

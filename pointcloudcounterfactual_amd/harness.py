@@ -1,0 +1,174 @@
+"""Training / inference step harness with the reference's layer shapes.
+
+NOT a port of the reference's model zoo: it exists so that BASELINE configs[3] (autoencoder training step,
+Chamfer + EMD) and configs[4] (batch-sharded counterfactual-style inference) can be measured end to end with the
+hot-path kernels in place.  Shapes follow the reference's source text:
+  encoder   DGCNN: EdgeConv 6->64, 128->64, 128->128, 256->256 (1x1 conv2d + BN2d [+ LeakyReLU 0.2]), dynamic kNN
+            (k=25) before every layer, max over k; cat -> 512; 1x1 conv1d 512->1024; global max
+            (src/module/encoders.py:31-59, src/module/layers.py:159-203, configs/.../default_data.yaml:12)
+  quantiser 256 codes x book 16 x dim 4, nearest code, straight-through gradient
+            (src/module/quantize.py:20-32, src/module/layers.py:220-237, configs/.../vqvae.yaml)
+  decoder   PCGen: sample 8 -> 64 (ReLU) -> 1024 (Hardtanh), multiplied by w; 8 component MLPs
+            1024->1024->256->16 (BN, ReLU, residual) -> 3; attention over components (gumbel-softmax tau 5);
+            graph_filtering k=4 (src/module/decoders.py:39-130, configs/.../pcgen.yaml)
+  loss      mean-Chamfer + match_cost + 8 * MSE(w_q, w_e)   (src/train/metrics_and_losses.py:21-90,258-266)
+  optimiser AdamW lr 4e-3, weight decay 1e-3                (configs/.../learn/default_learn.yaml)
+The dense layers are plain PyTorch-ROCm modules (rocBLAS / MIOpen); every kNN, gather, max-pool, Chamfer and EMD
+call goes through this package's HIP kernels.  The w-autoencoder transformer of the reference's counterfactual
+path (src/module/w_autoencoders.py) is out of scope and is not modelled.
+"""
+
+from __future__ import annotations
+
+import itertools
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from pointcloudcounterfactual_amd import neighbour_ops as ops
+from pointcloudcounterfactual_amd.losses import chamfer, match_cost
+
+
+class EdgeConv(nn.Module):
+    def __init__(self, cin: int, cout: int, act: bool = True) -> None:
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 1, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+        self.act = nn.LeakyReLU(0.2, inplace=True) if act else nn.Identity()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.act(self.bn(self.conv(x)))
+
+
+class PointsConv(nn.Module):
+    def __init__(self, cin: int, cout: int, act: nn.Module | None = None, bn: bool = True, residual: bool = False) -> None:
+        super().__init__()
+        self.conv = nn.Conv1d(cin, cout, 1, bias=not bn)
+        self.bn = nn.BatchNorm1d(cout) if bn else nn.Identity()
+        self.act = act if act is not None else nn.Identity()
+        self.residual = residual
+        self.cin, self.cout = cin, cout
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        y = self.act(self.bn(self.conv(x)))
+        if self.residual:  # layers.py:164-166
+            y = y + x.repeat_interleave(self.cout // self.cin + 1, 1)[:, : y.shape[1], ...]
+        return y
+
+
+class DGCNNEncoder(nn.Module):
+    h_dim = (64, 64, 128, 256)
+
+    def __init__(self, k: int = 25, w_dim: int = 1024) -> None:
+        super().__init__()
+        self.k = k
+        layers = [EdgeConv(6, self.h_dim[0], act=False)]
+        for cin, cout in itertools.pairwise(self.h_dim):
+            layers.append(EdgeConv(2 * cin, cout))
+        self.edge_convolutions = nn.ModuleList(layers)
+        self.final_conv = PointsConv(sum(self.h_dim), w_dim, bn=False)
+
+    def features(self, cloud: torch.Tensor) -> torch.Tensor:
+        x = cloud.transpose(2, 1).contiguous()
+        xs = []
+        for conv in self.edge_convolutions:
+            _idx, feat = ops.get_graph_features(x, torch.empty(0), self.k)  # dynamic graph every layer
+            x = conv(feat).max(dim=3)[0]
+            xs.append(x)
+        return self.final_conv(torch.cat(xs, dim=1).contiguous())
+
+    def forward(self, cloud: torch.Tensor) -> torch.Tensor:
+        return ops.global_max_pool(self.features(cloud))
+
+
+class DGCNNClassifier(nn.Module):
+    """classifier.py:18-66 with dgcnn.yaml: k=20, conv (64,64,128,256), feature 512, mlp (512,256), 40 classes."""
+
+    def __init__(self, k: int = 20, n_classes: int = 40) -> None:
+        super().__init__()
+        self.body = DGCNNEncoder(k=k, w_dim=512)
+        self.body.edge_convolutions[0] = EdgeConv(6, 64)
+        self.body.final_conv = PointsConv(512, 512, bn=True)
+        self.mlp = nn.Sequential(nn.Linear(1024, 512, bias=False), nn.BatchNorm1d(512), nn.LeakyReLU(0.2), nn.Dropout(0.5),
+                                 nn.Linear(512, 256, bias=False), nn.BatchNorm1d(256), nn.LeakyReLU(0.2), nn.Dropout(0.5),
+                                 nn.Linear(256, n_classes))
+
+    def forward(self, cloud: torch.Tensor) -> torch.Tensor:
+        feat = self.body.features(cloud)
+        if feat.requires_grad:
+            pooled = torch.cat((ops.global_max_pool(feat), feat.mean(dim=2)), 1)
+        else:
+            pooled = ops.global_max_mean_pool(feat)
+        return self.mlp(pooled)
+
+
+class _TransferGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, from_tensor, _to_tensor):  # noqa: ANN001
+        return from_tensor
+
+    @staticmethod
+    def backward(ctx, grad):  # noqa: ANN001
+        return None, grad.clone()
+
+
+class PCGenDecoder(nn.Module):
+    def __init__(self, w_dim: int = 1024, sample_dim: int = 8, n_components: int = 8, tau: float = 5.0,
+                 conv_dims: tuple[int, ...] = (1024, 256, 16), filtering: bool = True) -> None:
+        super().__init__()
+        self.sample_dim, self.n_components, self.tau, self.filtering = sample_dim, n_components, tau, filtering
+        self.map_sample = nn.Sequential(PointsConv(sample_dim, 64, nn.ReLU(inplace=True), bn=False),
+                                        PointsConv(64, w_dim, nn.Hardtanh(), bn=False))
+        self.group_conv = nn.ModuleList()
+        self.group_final = nn.ModuleList()
+        for _ in range(n_components):
+            dims = [w_dim, *conv_dims]
+            self.group_conv.append(nn.Sequential(*[PointsConv(a, b, nn.ReLU(inplace=True), residual=True)
+                                                   for a, b in itertools.pairwise(dims)]))
+            self.group_final.append(PointsConv(conv_dims[-1], 3, bn=False))
+        self.att = PointsConv(conv_dims[-1] * n_components, n_components, bn=False)
+
+    def forward(self, w: torch.Tensor, n_points: int) -> torch.Tensor:
+        x = torch.randn(w.shape[0], self.sample_dim, n_points, device=w.device)
+        x = w.unsqueeze(2) * self.map_sample(x)
+        feats = [g(x) for g in self.group_conv]
+        xs = torch.stack([f(h) for f, h in zip(self.group_final, feats, strict=True)], dim=3)
+        att = self.att(torch.cat(feats, dim=1).contiguous())
+        att = F.gumbel_softmax(att, tau=self.tau, dim=1) if self.training else torch.softmax(att / self.tau, dim=1)
+        x = (xs * att.transpose(2, 1).unsqueeze(1)).sum(3)
+        return ops.graph_filtering(x) if self.filtering else x
+
+
+class VQAutoencoder(nn.Module):
+    def __init__(self, n_points: int = 2048, k: int = 25, n_codes: int = 256, book_size: int = 16, dim: int = 4) -> None:
+        super().__init__()
+        self.n_points, self.n_codes, self.dim = n_points, n_codes, dim
+        self.encoder = DGCNNEncoder(k=k, w_dim=n_codes * dim)
+        self.decoder = PCGenDecoder(w_dim=n_codes * dim)
+        self.codebook = nn.Parameter(torch.randn(n_codes, book_size, dim))
+
+    def quantize(self, w_q: torch.Tensor) -> torch.Tensor:
+        b = w_q.shape[0]
+        x = w_q.view(b, self.n_codes, 1, self.dim)
+        dist = ((x - self.codebook.unsqueeze(0)) ** 2).sum(-1)             # [B, codes, book]
+        idx = dist.argmin(2)
+        return torch.gather(self.codebook.unsqueeze(0).expand(b, -1, -1, -1), 2,
+                            idx[..., None, None].expand(-1, -1, 1, self.dim)).reshape(b, -1)
+
+    def forward(self, cloud: torch.Tensor) -> dict[str, torch.Tensor]:
+        w_q = self.encoder(cloud)
+        w_e = self.quantize(w_q)
+        w = _TransferGrad.apply(w_e, w_q)
+        recon = self.decoder(w, self.n_points).transpose(2, 1).contiguous()
+        return {'recon': recon, 'w_q': w_q, 'w_e': w_e}
+
+
+def autoencoder_loss(out: dict[str, torch.Tensor], ref: torch.Tensor, c_embedding: float = 8.0) -> torch.Tensor:
+    """Per-sample loss [B]: mean-Chamfer + approximate EMD + c * MSE(w_q, w_e) (chamfer_emd.yaml)."""
+    embed = F.mse_loss(out['w_q'], out['w_e'], reduction='none').mean(dim=1)
+    return chamfer(out['recon'], ref) + match_cost(out['recon'], ref) + c_embedding * embed
+
+
+def make_optimizer(model: nn.Module) -> torch.optim.Optimizer:
+    return torch.optim.AdamW(model.parameters(), lr=4e-3, weight_decay=1e-3)
