@@ -67,10 +67,11 @@ constexpr int kBox = 16;          // points per bounding-box block (sorted order
 constexpr float kZeroExp = 151.f; // exp2(x) == 0 exactly for x <= -150 (below the smallest f32 subnormal)
 
 struct PhaseArgs {
-    int n_own, n_cand, tiles;          // tiles = ceil(n_own / (64 R))
+    int n_own, n_cand, tiles, batch;   // tiles = ceil(n_own / (64 R))
     int own_n4, cand_n4, own_nb, cand_nb;
     const float *own_soa, *cand_soa;   // [b][3][n4] Hilbert-sorted coordinates
-    const float *own_box, *cand_box;   // [b][nb][8]  (min xyz, pad, max xyz, pad) per 16 sorted points
+    const float *own_box, *cand_box;   // own: [b][ceil(n/64)][8] per 64 sorted points; cand: [b][nb][8] per 16 (min xyz,0,max xyz,0)
+    int own_nb64;
     const float *w0, *w1;              // per-candidate weights in sorted order (w0 may be null => w0c)
     long long w0_stride, w1_stride;    // per-sample strides in floats
     float w0c;
@@ -80,38 +81,169 @@ struct PhaseArgs {
     int level;                         // 0..8 (host bookkeeping only)
     float multiL, multiR;
     // epilogue operands, all indexed [sample * stride + owner (sorted position)]
-    float *remain;                     // remainL (CA/C) or remainR (B)
+    float *remain;                     // remainL (CA/C, updated in place by its owner) or remainR before pass B
+    float *remain_out;                 // pass B: remainR after the pass (a second buffer: other workgroups of the
+                                       // launch still read `remain` to find the live owners)
     long long remain_stride;
     const float *ratio_in;             // CA/C: ratioL_i
     float *ratio_out;                  // A: ratioL_0 ; B: ratioR_i ; CA: ratioL_{i+1}
     long long ratio_stride;            // per-sample stride of the level arrays
     int *dbg;                          // optional [2] counters: blocks visited / skipped (debug builds of the host)
+    int *dbg_stamp;                    // optional [8] in-kernel timestamps
 };
 
-template <int MODE, int R, int S, int CH, bool CULL>
+// Work-skipping variants of a phase launch.  All of them only drop terms that are EXACTLY zero:
+//   V_CULL  (fine levels): a (64-owner group, 16-candidate block) pair is skipped when the box distance makes
+//           every exp2(c*d2) underflow to 0;
+//   V_CCAND (pass C/A from level 2 on): candidates whose weights are all 0 are compacted away while staging --
+//           a query point whose capacity is used up has remainR == ratioR == 0 from then on (approxmatch.cu:108-109),
+//           typically 54 % of them by level 3 and 95 % by level 8;
+//   V_COWN  (pass B from level 3 on): the same exhausted points as OWNERS: their outputs are ratioR = 0,
+//           remainR = 0 whatever the sum is, so only the live owners are gathered into tiles (the level arrays
+//           are zero-filled beforehand) and workgroups beyond the live count exit.
+enum Var { V_PLAIN = 0, V_CULL = 1, V_CCAND = 2, V_COWN = 3 };
+
+// order-preserving compaction step shared by V_CCAND / V_COWN: position of this thread's element among the
+// flagged elements of the whole workgroup round (wave ballots + an S-entry LDS scan)
+template <int S>
+__device__ __forceinline__ int compact_pos(bool flag, int w, int lane, int *wave_cnt, int &round_total) {
+    const unsigned long long bal = __ballot(flag);
+    const int lane_off = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[w] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+        const int c = wave_cnt[i];
+        before += i < w ? c : 0;
+        total += c;
+    }
+    __syncthreads();  // wave_cnt may be rewritten by the next round
+    round_total = total;
+    return before + lane_off;
+}
+
+template <int MODE, int R, int S, int CH, int VAR>
 __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     constexpr int T = 64 * S;
     constexpr int TQ = 64 * R;
     constexpr int NW = (MODE == PH_CA) ? 2 : 1;
     constexpr bool W0_CONST = (MODE == PH_A);
+    constexpr bool CULL = VAR == V_CULL, CCAND = VAR == V_CCAND, COWN = VAR == V_COWN;
+    static_assert(!(CCAND && W0_CONST), "pass A of the first level has constant weights");
+    static_assert(TQ <= T, "one epilogue owner per thread");
     __shared__ __attribute__((aligned(16))) float lds_c[(3 + NW) * CH];  // x | y | z | w0 | (w1)
     __shared__ __attribute__((aligned(16))) float lds_bb[CULL ? (CH / kBox) * 8 : 8];
     __shared__ float red[NW][S][TQ];
+    __shared__ int own_idx[COWN ? TQ : 1];
+    __shared__ int wave_cnt[S];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int smp = blockIdx.x / a.tiles;
-    const int tile = blockIdx.x - smp * a.tiles;
+    // V_COWN packs the live owners into the low tiles: dispatch those first (tile-major order), so the workgroups
+    // that have nothing to do and exit after the scan are not in front of the ones that carry the launch
+    const int smp = COWN ? (int)(blockIdx.x % a.batch) : (int)(blockIdx.x / a.tiles);
+    const int tile = COWN ? (int)(blockIdx.x / a.batch) : (int)(blockIdx.x - smp * a.tiles);
     const float *O = a.own_soa + (size_t)smp * 3 * a.own_n4;
     const float *C = a.cand_soa + (size_t)smp * 3 * a.cand_n4;
     const float *W0 = W0_CONST ? nullptr : a.w0 + (size_t)smp * a.w0_stride;
     const float *W1 = (NW == 2) ? a.w1 + (size_t)smp * a.w1_stride : nullptr;
 
+    // ---- which owners does this workgroup hold? ----
+    unsigned long long stamp0 = 0;
+    if (COWN && a.dbg_stamp) {
+        stamp0 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) atomicMin(reinterpret_cast<unsigned *>(&a.dbg_stamp[8]), (unsigned)stamp0);
+    }
+#define PCC_STAMP(k) do { if (COWN && a.dbg_stamp && blockIdx.x == 0 && tid == 0) a.dbg_stamp[(k)] = (int)(__builtin_amdgcn_s_memrealtime() - stamp0); } while (0)
+    int n_valid = min(TQ, a.n_own - tile * TQ);  // owners of this tile (sorted positions tile*TQ ...)
+    if (COWN) {
+        // live owners (remain != 0) of the sample, in order; this workgroup takes the tile-th group of TQ.
+        // Every thread owns a contiguous run of the owner array: one count pass, ONE block scan, one assign pass.
+        const float *rem = a.remain + (size_t)smp * a.remain_stride;
+        const int lo = tile * TQ, hi = lo + TQ;
+        // fast path: <= 16 owners per thread, fetched as four independent float4 loads (the rows are padded to a
+        // multiple of 4 with zeros == exhausted) and kept in registers for the assign pass
+        constexpr int V4 = 4;
+        const bool fast = a.own_n4 <= 4 * V4 * T;
+        const int per = fast ? 4 * V4 : (a.n_own + T - 1) / T;
+        const int beg = min(tid * per, fast ? a.own_n4 : a.n_own), end = min(beg + per, fast ? a.own_n4 : a.n_own);
+        float4 rv[V4];
+        int mine = 0;
+        if (fast) {
+#pragma unroll
+            for (int v = 0; v < V4; v++) {
+                rv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (beg + 4 * v < end) rv[v] = *reinterpret_cast<const float4 *>(rem + beg + 4 * v);
+            }
+#pragma unroll
+            for (int v = 0; v < V4; v++)
+                mine += (rv[v].x != 0.f) + (rv[v].y != 0.f) + (rv[v].z != 0.f) + (rv[v].w != 0.f);
+        } else {
+            for (int i = beg; i < end; i++) mine += rem[i] != 0.f ? 1 : 0;
+        }
+        // exclusive scan of `mine` over the workgroup: wave scan + S-entry LDS scan
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            incl += lane >= off ? v : 0;
+        }
+        if (lane == 63) wave_cnt[w] = incl;
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const int c = wave_cnt[i];
+            before += i < w ? c : 0;
+            total += c;
+        }
+        int pos = before + incl - mine;
+        auto place = [&](int i, bool flag) {
+            if (flag) {
+                if (pos >= lo && pos < hi) own_idx[pos - lo] = i;
+                pos++;
+            } else if (tile == 0 && i < a.n_own) {
+                // an exhausted owner keeps remainR = 0 (and ratioR = 0 from the zero-filled level array); the
+                // first workgroup of the sample carries the zero over into the output buffer
+                a.remain_out[(size_t)smp * a.remain_stride + i] = 0.f;
+            }
+        };
+        if (fast) {
+#pragma unroll
+            for (int v = 0; v < V4; v++) {
+                const int i = beg + 4 * v;
+                if (i < end) {
+                    place(i + 0, rv[v].x != 0.f);
+                    place(i + 1, rv[v].y != 0.f);
+                    place(i + 2, rv[v].z != 0.f);
+                    place(i + 3, rv[v].w != 0.f);
+                }
+            }
+        } else {
+            for (int i = beg; i < end; i++) place(i, rem[i] != 0.f);
+        }
+        if (a.dbg && tile == 0 && tid == 0) {
+            atomicAdd(&a.dbg[0], a.n_own);
+            atomicAdd(&a.dbg[1], a.n_own - total);
+        }
+        n_valid = min(TQ, total - lo);
+        if (n_valid <= 0 || a.level < 0) {
+            if (a.dbg_stamp && tid == 0) atomicMax(reinterpret_cast<unsigned *>(&a.dbg_stamp[9]), (unsigned)__builtin_amdgcn_s_memrealtime());
+            return;  // wave-uniform: nothing live in this tile
+        }
+        __syncthreads();
+    }
+    PCC_STAMP(0);
+    int own_e = -1;  // sorted position of the owner this THREAD finishes in the epilogue
+    if (tid < TQ && tid < n_valid) own_e = COWN ? own_idx[tid] : tile * TQ + tid;
+
     float ox[R], oy[R], oz[R], s0[R], s1[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        int o = tile * TQ + r * 64 + lane;
+        const int e = r * 64 + lane;
+        int o = COWN ? own_idx[e < n_valid ? e : 0] : tile * TQ + e;
         o = o < a.n_own ? o : a.n_own - 1;
         ox[r] = O[o];
         oy[r] = O[a.own_n4 + o];
@@ -119,26 +251,25 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
         s0[r] = 0.f;
         s1[r] = 0.f;
     }
-    // bounding boxes of the R groups of 64 owners this workgroup holds (wave-uniform): each is the union of
-    // four 16-point block boxes of the sorted order
+    // bounding boxes of the R groups of 64 owners this workgroup holds (wave-uniform), precomputed by the sort
     float olx[R], oly[R], olz[R], ohx[R], ohy[R], ohz[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         olx[r] = oly[r] = olz[r] = __builtin_inff();
         ohx[r] = ohy[r] = ohz[r] = -__builtin_inff();
         if (CULL) {
-            const float *ob = a.own_box + (size_t)smp * a.own_nb * 8;
-            const int b0 = (tile * TQ + r * 64) / kBox;
-            const int b1 = min(b0 + 64 / kBox, a.own_nb);
-            for (int bb = b0; bb < b1; bb++) {
-                olx[r] = fminf(olx[r], ob[bb * 8 + 0]);
-                oly[r] = fminf(oly[r], ob[bb * 8 + 1]);
-                olz[r] = fminf(olz[r], ob[bb * 8 + 2]);
-                ohx[r] = fmaxf(ohx[r], ob[bb * 8 + 4]);
-                ohy[r] = fmaxf(ohy[r], ob[bb * 8 + 5]);
-                ohz[r] = fmaxf(ohz[r], ob[bb * 8 + 6]);
-            }
+            const int g64 = min((tile * TQ + r * 64) / 64, a.own_nb64 - 1);
+            const float4 *ob = reinterpret_cast<const float4 *>(a.own_box + ((size_t)smp * a.own_nb64 + g64) * 8);
+            const float4 lo = ob[0], hi = ob[1];
+            olx[r] = lo.x; oly[r] = lo.y; olz[r] = lo.z;
+            ohx[r] = hi.x; ohy[r] = hi.y; ohz[r] = hi.z;
         }
+    }
+    // operands of the epilogue do not depend on the pair loop: fetch them now, behind the staging traffic
+    float pre_rem = 0.f, pre_ratio = 0.f;
+    if (own_e >= 0) {
+        if (MODE != PH_A && !a.first) pre_rem = a.remain[(size_t)smp * a.remain_stride + own_e];
+        if (MODE == PH_CA || MODE == PH_C) pre_ratio = a.ratio_in[(size_t)smp * a.ratio_stride + own_e];
     }
     const float4 *X4 = reinterpret_cast<const float4 *>(lds_c);
     const float4 *Y4 = X4 + CH / 4;
@@ -150,29 +281,73 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
 
     for (int q0 = 0; q0 < a.n_cand; q0 += CH) {
         const int cnt = min(CH, a.n_cand - q0);
-        const int ngroups = (cnt + 3) / 4;
-        const int nblk = (cnt + kBox - 1) / kBox;
+        int ngroups = (cnt + 3) / 4;
         if (q0) __syncthreads();
-        // sorted SoA rows are padded to a multiple of 4 with zeros: straight float4 copies
-        {
+        if (CCAND) {
+            // stage only the candidates that can contribute (some weight != 0), order preserved
+            int running = 0;
+            for (int base = 0; base < cnt; base += T) {
+                const int i = base + tid;
+                const bool in = i < cnt;
+                const float v0 = in ? W0[q0 + i] : 0.f;
+                const float v1 = (NW == 2 && in) ? W1[q0 + i] : 0.f;
+                const bool flag = v0 != 0.f || v1 != 0.f;
+                const float vx = in ? C[q0 + i] : 0.f;
+                const float vy = in ? C[(size_t)a.cand_n4 + q0 + i] : 0.f;
+                const float vz = in ? C[(size_t)2 * a.cand_n4 + q0 + i] : 0.f;
+                int round_total;
+                const int pos = running + compact_pos<S>(flag, w, lane, wave_cnt, round_total);
+                if (flag) {
+                    lds_c[pos] = vx;
+                    lds_c[CH + pos] = vy;
+                    lds_c[2 * CH + pos] = vz;
+                    lds_c[3 * CH + pos] = v0;
+                    if (NW == 2) lds_c[4 * CH + pos] = v1;
+                }
+                running += round_total;
+            }
+            ngroups = (running + 3) / 4;
+            if (tid < ngroups * 4 - running) {  // zero the tail of the last group
+                const int pos = running + tid;
+                lds_c[pos] = lds_c[CH + pos] = lds_c[2 * CH + pos] = lds_c[3 * CH + pos] = 0.f;
+                if (NW == 2) lds_c[4 * CH + pos] = 0.f;
+            }
+        } else {
+            // sorted SoA rows and the weight rows are padded to a multiple of 4 (zeros): straight float4 copies,
+            // all loads of a thread issued before the first LDS store
             float4 *dst4 = reinterpret_cast<float4 *>(lds_c);
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const float4 *src4 = reinterpret_cast<const float4 *>(C + (size_t)ch * a.cand_n4 + q0);
-                for (int i = tid; i < ngroups; i += T) dst4[ch * (CH / 4) + i] = src4[i];
+            const float4 *sx = reinterpret_cast<const float4 *>(C + q0);
+            const float4 *sy = reinterpret_cast<const float4 *>(C + (size_t)a.cand_n4 + q0);
+            const float4 *sz = reinterpret_cast<const float4 *>(C + (size_t)2 * a.cand_n4 + q0);
+            const float4 *sw0 = W0_CONST ? nullptr : reinterpret_cast<const float4 *>(W0 + q0);
+            const float4 *sw1 = NW == 2 ? reinterpret_cast<const float4 *>(W1 + q0) : nullptr;
+            for (int i = tid; i < ngroups; i += T) {
+                const float4 vx = sx[i], vy = sy[i], vz = sz[i];
+                float4 v0 = make_float4(a.w0c, a.w0c, a.w0c, a.w0c), v1 = v0;
+                if (!W0_CONST) v0 = sw0[i];
+                if (NW == 2) v1 = sw1[i];
+                if (W0_CONST && i * 4 + 3 >= cnt) {  // padded candidates must weigh 0
+                    v0.x = i * 4 + 0 < cnt ? v0.x : 0.f;
+                    v0.y = i * 4 + 1 < cnt ? v0.y : 0.f;
+                    v0.z = i * 4 + 2 < cnt ? v0.z : 0.f;
+                    v0.w = 0.f;
+                }
+                dst4[i] = vx;
+                dst4[CH / 4 + i] = vy;
+                dst4[2 * (CH / 4) + i] = vz;
+                dst4[3 * (CH / 4) + i] = v0;
+                if (NW == 2) dst4[4 * (CH / 4) + i] = v1;
             }
         }
-        for (int i = tid; i < ngroups * 4; i += T) {
-            const bool ok = i < cnt;
-            lds_c[3 * CH + i] = ok ? (W0_CONST ? a.w0c : W0[q0 + i]) : 0.f;  // padded candidates weigh 0
-            if (NW == 2) lds_c[4 * CH + i] = ok ? W1[q0 + i] : 0.f;
-        }
+        PCC_STAMP(1);
+        const int nblk = (ngroups + 3) / 4;  // blocks of 16 candidates (4 groups)
         if (CULL) {
             const float *cb = a.cand_box + ((size_t)smp * a.cand_nb + q0 / kBox) * 8;
             for (int i = tid; i < nblk * 8; i += T) lds_bb[i] = cb[i];
         }
         __syncthreads();
-        // blocks are dealt round-robin to the S waves: a contiguous slice of the Morton order is one compact
+        PCC_STAMP(2);
+        // blocks are dealt round-robin to the S waves: a contiguous slice of the Hilbert order is one compact
         // region, so contiguous slices would make culling all-or-nothing per wave and leave the workgroup
         // waiting for its nearest slice
         for (int blk = w; blk < nblk; blk += S) {
@@ -228,15 +403,19 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
             }
         }
     }
+    PCC_STAMP(3);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         red[0][w][r * 64 + lane] = s0[r];
         if (NW == 2) red[1][w][r * 64 + lane] = s1[r];
     }
     __syncthreads();
-    for (int e = tid; e < TQ; e += T) {
-        const int o = tile * TQ + e;
-        if (o >= a.n_own) continue;
+    PCC_STAMP(4);
+    if (COWN && a.dbg_stamp && tid == 0) atomicMax(reinterpret_cast<unsigned *>(&a.dbg_stamp[10]), (unsigned)__builtin_amdgcn_s_memrealtime());
+    if (own_e < 0) return;
+    {
+        const int e = tid;
+        const int o = own_e;
         float t0 = red[0][0][e], t1 = 0.f;
         if (NW == 2) t1 = red[1][0][e];
 #pragma unroll
@@ -249,17 +428,16 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
             a.ratio_out[(size_t)smp * a.ratio_stride + o] = a.multiL / (1e-9f + t0);
         } else if (MODE == PH_B) {
             // approxmatch.cu:106-109
-            float *rem = a.remain + (size_t)smp * a.remain_stride + o;
-            const float rR = a.first ? a.multiR : *rem;
+            const float rR = a.first ? a.multiR : pre_rem;
             const float sumr = t0 * rR;
             const float consumption = __builtin_fminf(rR / (sumr + 1e-9f), 1.0f);
             a.ratio_out[(size_t)smp * a.ratio_stride + o] = consumption * rR;
-            *rem = __builtin_fmaxf(0.0f, rR - sumr);
+            a.remain_out[(size_t)smp * a.remain_stride + o] = __builtin_fmaxf(0.0f, rR - sumr);
         } else {
             // pass C: suml = sum_l e*ratioL[k]*ratioR[l] ; remainL = max(0, remainL - suml)   :154-162
             float *rem = a.remain + (size_t)smp * a.remain_stride + o;
-            const float rl = a.ratio_in[(size_t)smp * a.ratio_stride + o];
-            const float rL = a.first ? a.multiL : *rem;
+            const float rl = pre_ratio;
+            const float rL = a.first ? a.multiL : pre_rem;
             const float left = __builtin_fmaxf(0.0f, rL - rl * t0);
             *rem = left;
             // pass A of the next level: ratioL' = remainL / (1e-9 + sum_l e'*remainR[l])       :37,61
@@ -319,6 +497,8 @@ struct SortArgs {  // one entry per cloud; blockIdx.y selects it
     float *soa[2];
     int *rank[2];
     float *box[2];
+    float *box64[2];
+    int nb64[2];
 };
 
 // Bitonic sort of NPAD = kSortT*SLOTS 32-bit keys held in registers (element i = tid + kSortT*slot) by a
@@ -377,6 +557,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     float *so = a.soa[which] + (size_t)smp * 3 * n4;
     int *rk = a.rank[which] + (size_t)smp * n;
     float *bx = a.box[which] + (size_t)smp * nb * 8;
+    float *bx64 = a.box64[which] + (size_t)smp * a.nb64[which] * 8;
     int idx_bits = 10;
     while ((1 << idx_bits) < npad) idx_bits++;  // npad >= 1024
     const unsigned idx_mask = (1u << idx_bits) - 1;
@@ -467,32 +648,50 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
             dst[0] = make_float4(l0, l1, l2, 0.f);
             dst[1] = make_float4(h0, h1, h2, 0.f);
         }
+        // a wave holds 64 consecutive sorted points: two more butterfly steps give the owner-group box
+#pragma unroll
+        for (int off = kBox; off < 64; off <<= 1) {
+            l0 = fminf(l0, __shfl_xor(l0, off, 64));
+            l1 = fminf(l1, __shfl_xor(l1, off, 64));
+            l2 = fminf(l2, __shfl_xor(l2, off, 64));
+            h0 = fmaxf(h0, __shfl_xor(h0, off, 64));
+            h1 = fmaxf(h1, __shfl_xor(h1, off, 64));
+            h2 = fmaxf(h2, __shfl_xor(h2, off, 64));
+        }
+        if ((s & 63) == 0 && s / 64 < a.nb64[which]) {
+            float4 *dst = reinterpret_cast<float4 *>(bx64 + (size_t)(s / 64) * 8);
+            dst[0] = make_float4(l0, l1, l2, 0.f);
+            dst[1] = make_float4(h0, h1, h2, 0.f);
+        }
     }
 }
 
 // The phases run in Hilbert-sorted index space; this puts the nine (ratioL | ratioR) level vectors back into
 // the caller's point order for the materialise pass (contiguous loads there) and fills
 // temp = remainL | remainR | ratioL | ratioR of the last level (approxmatch.cu:4).
-__global__ __launch_bounds__(256) void am_unpermute_kernel(int n, int m, const float *__restrict__ lv_sorted,
+__global__ __launch_bounds__(256) void am_unpermute_kernel(int n, int m, int n4, int m4,
+                                                            const float *__restrict__ lv_sorted,
                                                             const float *__restrict__ rem_sorted,
                                                             const int *__restrict__ rank1,
                                                             const int *__restrict__ rank2,
                                                             float *__restrict__ lv, float *__restrict__ temp) {
+    // sorted-space rows are [ratioL (n4) | ratioR (m4)] (16-byte aligned halves); outputs are dense [n | m]
     const int smp = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n + m) return;
-    const int s = i < n ? rank1[(size_t)smp * n + i] : n + rank2[(size_t)smp * m + (i - n)];
-    const size_t nm = (size_t)n + m;
-    const float *src = lv_sorted + (size_t)smp * kLevels * nm;
+    const int s = i < n ? rank1[(size_t)smp * n + i] : n4 + rank2[(size_t)smp * m + (i - n)];
+    const size_t nm = (size_t)n + m, nm4 = (size_t)n4 + m4;
+    const float *src = lv_sorted + (size_t)smp * kLevels * nm4;
     float *dst = lv + (size_t)smp * kLevels * nm;
     float last = 0.f;
 #pragma unroll
     for (int l = 0; l < kLevels; l++) {
-        last = src[(size_t)l * nm + s];
+        last = src[(size_t)l * nm4 + s];
         dst[(size_t)l * nm + i] = last;
     }
+    // remain row: remainL (n4) | remainR ping (m4) | pong (m4); the nine passes B leave the final remainR in pong
     float *tb = temp + (size_t)smp * 2 * nm;
-    tb[i] = rem_sorted[(size_t)smp * nm + s];
+    tb[i] = rem_sorted[(size_t)smp * (nm4 + m4) + (i < n ? s : s + m4)];
     tb[nm + i] = last;
 }
 
@@ -549,18 +748,30 @@ __global__ __launch_bounds__(256) void am_materialise_kernel(int n, int m, const
     for (int li = w; li < lcnt; li += 4) {
         const float4 A = lds_l[li][0], B = lds_l[li][1], Cc = lds_l[li][2];
         const float rr[kLevels] = {A.w, B.x, B.y, B.z, B.w, Cc.x, Cc.y, Cc.z, Cc.w};
+        // A query point whose capacity is used up has ratioR == 0 exactly at every later level (remainR is
+        // clamped to 0, approxmatch.cu:109, and ratioR = consumption * remainR, :108): that level adds exactly 0
+        // to the whole row, so its exponentials are skipped (wave-uniform).  Typically 4 of 9 levels are live.
+        int live[kLevels];
+#pragma unroll
+        for (int i = 0; i < kLevels; i++) live[i] = __builtin_amdgcn_readfirstlane((int)(rr[i] != 0.f));
+        float d[4], acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            d[q] = sq3(A.x - x1[q], A.y - y1[q], A.z - z1[q]);
+            acc[q] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < kLevels; i++) {
+            if (live[i]) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] += (fast_exp2(lc.c[i] * d[q]) * rl[i][q]) * rr[i];
+            }
+        }
         float out[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const float d = sq3(A.x - x1[q], A.y - y1[q], A.z - z1[q]);
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < kLevels; i++) {
-                const float wgt = (fast_exp2(lc.c[i] * d) * rl[i][q]) * rr[i];
-                acc += wgt;
-            }
-            out[q] = acc;
-            if (COST && k0 + q < n) csum = __builtin_fmaf(acc, __builtin_amdgcn_sqrtf(d), csum);
+            out[q] = acc[q];
+            if (COST && k0 + q < n) csum = __builtin_fmaf(acc[q], __builtin_amdgcn_sqrtf(d[q]), csum);
         }
         float *row = match + ((size_t)smp * m + (l0 + li)) * n;
         if (VEC) {
@@ -938,7 +1149,7 @@ static int phase_cfg_override() {
     }();
     return v;
 }
-static bool cull_enabled() {
+static bool cull_enabled() {  // PCC_AM_NOCULL=1 disables every work-skipping variant (A/B measurements)
     static const bool v = [] {
         const char *e = std::getenv("PCC_AM_NOCULL");
         return !(e && e[0] == '1');
@@ -960,38 +1171,55 @@ const char *phase_name(int level) {
 }
 
 template <int MODE, int R, int S>
-int launch_phase_rs(PhaseArgs a, int b, bool cull, hipStream_t st, const char *what) {
+int launch_phase_rs(PhaseArgs a, int b, int var, hipStream_t st, const char *what) {
     a.tiles = pcc::ceil_div(a.n_own, 64 * R);
+    a.batch = b;
     const long long grid = (long long)b * a.tiles;
     if (grid > 0x7fffffffLL) return pcc::invalid("approxmatch: grid too large");
     {
-        pcc::ProfScope prof(phase_name<MODE>(a.level), st);
-        if (cull)
-            hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, true>), dim3((unsigned)grid), dim3(64 * S), 0, st, a);
-        else
-            hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, false>), dim3((unsigned)grid), dim3(64 * S), 0, st, a);
+        pcc::ProfScope prof(phase_name<MODE>(a.level < 0 ? 8 : a.level), st);
+        const dim3 g((unsigned)grid), blk(64 * S);
+        // only the combinations the schedule uses are instantiated
+        if (var == V_CULL) hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, V_CULL>), g, blk, 0, st, a);
+        else if (var == V_CCAND && (MODE == PH_CA || MODE == PH_C))
+            hipLaunchKernelGGL((am_phase_kernel<(MODE == PH_CA || MODE == PH_C) ? MODE : PH_C, R, S, kPhCH, V_CCAND>), g, blk, 0, st, a);
+        else if (var == V_COWN && MODE == PH_B)
+            hipLaunchKernelGGL((am_phase_kernel<PH_B, R, S, kPhCH, V_COWN>), g, blk, 0, st, a);
+        else hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, V_PLAIN>), g, blk, 0, st, a);
     }
     return pcc::check_launch(what);
 }
 
 template <int MODE>
-int launch_phase(const PhaseArgs &a, int b, bool cull, hipStream_t st, const char *what) {
+int launch_phase(const PhaseArgs &a, int b, int var, hipStream_t st, const char *what) {
     int cfg = phase_cfg_override();
     if (cfg == 0) {
         const long long owners = (long long)b * a.n_own;
         // waves = owners / (64 R) * S ; aim for >= 4096
-        if (owners >= 4LL * 65536) cfg = 44;
-        else if (owners >= 2LL * 65536) cfg = 48;
+        if (owners >= 4LL * 65536) cfg = 48;
         else if (owners >= 65536) cfg = 28;
         else cfg = 18;
     }
+    // Owner compaction packs the live owners into the first tiles; a full tile takes as long as before (just on
+    // fewer CUs), so these launches use the smallest tile (64 owners x 4 waves): the same work per wave as the
+    // default shape, and with a fraction f of the owners live only f of the wave slots are contended.
+    if (var == V_COWN && cfg != 216) {
+        static const int cown_cfg = [] {
+            const char *e = std::getenv("PCC_AM_COWN_CFG");
+            return e ? std::atoi(e) : 18;
+        }();
+        switch (cown_cfg) {
+        case 116: return launch_phase_rs<MODE, 1, 16>(a, b, var, st, what);
+        case 18: return launch_phase_rs<MODE, 1, 8>(a, b, var, st, what);
+        case 28: return launch_phase_rs<MODE, 2, 8>(a, b, var, st, what);
+        default: return launch_phase_rs<MODE, 1, 4>(a, b, var, st, what);
+        }
+    }
     switch (cfg) {
-    case 44: return launch_phase_rs<MODE, 4, 4>(a, b, cull, st, what);
-    case 48: return launch_phase_rs<MODE, 4, 8>(a, b, cull, st, what);
-    case 28: return launch_phase_rs<MODE, 2, 8>(a, b, cull, st, what);
-    case 216: return launch_phase_rs<MODE, 2, 16>(a, b, cull, st, what);
-    case 116: return launch_phase_rs<MODE, 1, 16>(a, b, cull, st, what);
-    default: return launch_phase_rs<MODE, 1, 8>(a, b, cull, st, what);
+    case 48: return launch_phase_rs<MODE, 4, 8>(a, b, var, st, what);
+    case 28: return launch_phase_rs<MODE, 2, 8>(a, b, var, st, what);
+    case 216: return launch_phase_rs<MODE, 2, 16>(a, b, var, st, what);
+    default: return launch_phase_rs<MODE, 1, 8>(a, b, var, st, what);
     }
 }
 
@@ -1030,14 +1258,16 @@ size_t cost_parts(int n, int m) { return (size_t)pcc::ceil_div(n, kMatKT) * pcc:
 
 // Workspace carve (bytes, every section 16-byte aligned).
 struct WsLayout {
-    int n4, m4, nb1, nb2;
-    size_t soa1, soa2, rank1, rank2, box1, box2, rem, lv, lv_orig, cpart, total;
+    int n4, m4, nb1, nb2, nb64_1, nb64_2;
+    size_t soa1, soa2, rank1, rank2, box1, box2, box64_1, box64_2, rem, lv, lv_orig, cpart, total;
     WsLayout(int b, int n, int m) {
         auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
         n4 = (n + 3) & ~3;
         m4 = (m + 3) & ~3;
         nb1 = pcc::ceil_div(n, kBox);
         nb2 = pcc::ceil_div(m, kBox);
+        nb64_1 = pcc::ceil_div(n, 64);
+        nb64_2 = pcc::ceil_div(m, 64);
         size_t o = 0;
         soa1 = o; o = up(o + (size_t)b * 3 * n4 * 4);
         soa2 = o; o = up(o + (size_t)b * 3 * m4 * 4);
@@ -1045,8 +1275,10 @@ struct WsLayout {
         rank2 = o; o = up(o + (size_t)b * m * 4);
         box1 = o; o = up(o + (size_t)b * nb1 * 8 * 4);
         box2 = o; o = up(o + (size_t)b * nb2 * 8 * 4);
-        rem = o; o = up(o + (size_t)b * ((size_t)n + m) * 4);
-        lv = o; o = up(o + (size_t)b * kLevels * ((size_t)n + m) * 4);
+        box64_1 = o; o = up(o + (size_t)b * nb64_1 * 8 * 4);
+        box64_2 = o; o = up(o + (size_t)b * nb64_2 * 8 * 4);
+        rem = o; o = up(o + (size_t)b * ((size_t)n4 + 2 * (size_t)m4) * 4);    // sorted space: remainL | remainR x2
+        lv = o; o = up(o + (size_t)b * kLevels * ((size_t)n4 + m4) * 4);      // sorted space, padded halves
         lv_orig = o; o = up(o + (size_t)b * kLevels * ((size_t)n + m) * 4);
         cpart = o; o = up(o + (size_t)b * cost_parts(n, m) * 4);
         total = o;
@@ -1054,7 +1286,7 @@ struct WsLayout {
 };
 
 int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const float *xyz2, float *soa1, float *soa2,
-                int *rank1, int *rank2, float *box1, float *box2, hipStream_t st) {
+                int *rank1, int *rank2, float *box1, float *box2, float *box64_1, float *box64_2, hipStream_t st) {
     SortArgs a{};
     const int nn[2] = {n, m};
     int slots = 4;
@@ -1071,6 +1303,7 @@ int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const
     a.n4[0] = L.n4; a.n4[1] = L.m4; a.nb[0] = L.nb1; a.nb[1] = L.nb2;
     a.xyz[0] = xyz1; a.xyz[1] = xyz2; a.soa[0] = soa1; a.soa[1] = soa2;
     a.rank[0] = rank1; a.rank[1] = rank2; a.box[0] = box1; a.box[1] = box2;
+    a.box64[0] = box64_1; a.box64[1] = box64_2; a.nb64[0] = L.nb64_1; a.nb64[1] = L.nb64_2;
     pcc::ProfScope prof("am_sort_kernel", st);
     const dim3 grid(b, 2);
     switch (slots) {
@@ -1092,6 +1325,7 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
     float *soa1 = reinterpret_cast<float *>(base + L.soa1), *soa2 = reinterpret_cast<float *>(base + L.soa2);
     int *rank1 = reinterpret_cast<int *>(base + L.rank1), *rank2 = reinterpret_cast<int *>(base + L.rank2);
     float *box1 = reinterpret_cast<float *>(base + L.box1), *box2 = reinterpret_cast<float *>(base + L.box2);
+    float *box64_1 = reinterpret_cast<float *>(base + L.box64_1), *box64_2 = reinterpret_cast<float *>(base + L.box64_2);
     float *rem = reinterpret_cast<float *>(base + L.rem);
     float *lv = reinterpret_cast<float *>(base + L.lv);
     float *lv_orig = reinterpret_cast<float *>(base + L.lv_orig);
@@ -1100,10 +1334,21 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
     float multiL, multiR;  // approxmatch.cu:6-12 (integer division)
     if (n >= m) { multiL = 1; multiR = (float)(n / m); }
     else { multiL = (float)(m / n); multiR = 1; }
-    const long long nm = (long long)n + m;
+    const long long nm4 = (long long)L.n4 + L.m4;  // sorted-space level row: ratioL (n4) | ratioR (m4)
+    const long long rs = (long long)L.n4 + 2LL * L.m4;  // remain row: remainL (n4) | remainR ping (m4) | pong (m4)
 
-    int rc = sort_clouds(b, L, n, m, xyz1, xyz2, soa1, soa2, rank1, rank2, box1, box2, st);
+    int rc = sort_clouds(b, L, n, m, xyz1, xyz2, soa1, soa2, rank1, rank2, box1, box2, box64_1, box64_2, st);
     if (rc) return rc;
+    // the padded tails of the weight rows are staged as float4: they must be finite (their candidates sit at
+    // the origin with these weights); zero them once
+    // ... and V_COWN relies on zero-filled level arrays for the exhausted owners it never touches
+    {
+        hipError_t e = hipMemsetAsync(rem, 0, (size_t)b * (rs + kLevels * nm4) * sizeof(float), st);
+        if (e != hipSuccess) {
+            pcc::set_error((int)e, "approxmatch: memset failed");
+            return (int)e;
+        }
+    }
 
     // A level is worth culling while its zero radius is small against the cloud; beyond level 3 (|c| < 92,
     // radius > 1.2) nothing can be skipped for unit-ball clouds and the box test would be pure overhead.
@@ -1112,15 +1357,18 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         return e ? (float)std::atof(e) : 1.0f;
     }();
     auto cut_of = [&](int i) { return cut_scale * kZeroExp / -lc.c[i]; };
-    auto cull_at = [&](int i) { return cull_enabled() && i <= 3; };
+    // schedule of the work-skipping variants (see enum Var): box culling while the zero radius is small against the
+    // cloud (levels 0-3: beyond that nothing can be skipped for unit-ball clouds), exhausted-point compaction after
+    auto var_b = [&](int i) { return !cull_enabled() ? V_PLAIN : i <= 2 ? V_CULL : V_COWN; };
+    auto var_ca = [&](int i) { return !cull_enabled() ? V_PLAIN : i <= 1 ? V_CULL : V_CCAND; };  // culls at level i+1
 
     auto owner1 = [&](PhaseArgs &a) {  // owners = set1, candidates = set2
         a.n_own = n; a.n_cand = m; a.own_n4 = L.n4; a.cand_n4 = L.m4; a.own_nb = L.nb1; a.cand_nb = L.nb2;
-        a.own_soa = soa1; a.cand_soa = soa2; a.own_box = box1; a.cand_box = box2;
+        a.own_soa = soa1; a.cand_soa = soa2; a.own_box = box64_1; a.own_nb64 = L.nb64_1; a.cand_box = box2;
     };
     auto owner2 = [&](PhaseArgs &a) {  // owners = set2, candidates = set1
         a.n_own = m; a.n_cand = n; a.own_n4 = L.m4; a.cand_n4 = L.n4; a.own_nb = L.nb2; a.cand_nb = L.nb1;
-        a.own_soa = soa2; a.cand_soa = soa1; a.own_box = box2; a.cand_box = box1;
+        a.own_soa = soa2; a.cand_soa = soa1; a.own_box = box64_2; a.own_nb64 = L.nb64_2; a.cand_box = box1;
     };
 
     static int *dbg_counters = [] {
@@ -1128,6 +1376,7 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         const char *e = std::getenv("PCC_AM_DEBUG");
         if (e && e[0] == '1' && hipMalloc(reinterpret_cast<void **>(&p), 64 * sizeof(int)) == hipSuccess)
             (void)hipMemset(p, 0, 64 * sizeof(int));
+        if (p) (void)hipMemset(p + 48, 0xff, sizeof(int));
         return p;
     }();
     PhaseArgs a{};
@@ -1135,36 +1384,38 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
     a.multiL = multiL; a.multiR = multiR;
     owner1(a);
     a.w0 = nullptr; a.w0c = multiR; a.c0 = lc.c[0]; a.first = 1; a.cut2 = cut_of(0);
-    a.ratio_out = lv; a.ratio_stride = kLevels * nm;
-    rc = launch_phase<PH_A>(a, b, cull_at(0), st, "approxmatch(A)");
+    a.ratio_out = lv; a.ratio_stride = kLevels * nm4;
+    rc = launch_phase<PH_A>(a, b, cull_enabled() ? V_CULL : V_PLAIN, st, "approxmatch(A)");
     if (rc) return rc;
     for (int i = 0; i < kLevels; i++) {
-        float *ratioL = lv + (size_t)i * nm, *ratioR = ratioL + n;
+        float *ratioL = lv + (size_t)i * nm4, *ratioR = ratioL + L.n4;
         PhaseArgs pb{};
         pb.dbg = dbg_counters ? dbg_counters + 2 + 4 * i : nullptr;
+        pb.dbg_stamp = (dbg_counters && i == 8) ? dbg_counters + 40 : nullptr;
         pb.multiL = multiL; pb.multiR = multiR; pb.first = (i == 0); pb.level = i;
+        if (std::getenv("PCC_AM_DBGRET") && i >= 3) pb.level = -1;
         owner2(pb);
-        pb.w0 = ratioL; pb.w0_stride = kLevels * nm; pb.c0 = lc.c[i]; pb.cut2 = cut_of(i);
-        pb.remain = rem + n; pb.remain_stride = nm;
-        pb.ratio_out = ratioR; pb.ratio_stride = kLevels * nm;
-        rc = launch_phase<PH_B>(pb, b, cull_at(i), st, "approxmatch(B)");
+        pb.w0 = ratioL; pb.w0_stride = kLevels * nm4; pb.c0 = lc.c[i]; pb.cut2 = cut_of(i);
+        pb.remain = rem + L.n4 + (i & 1) * L.m4; pb.remain_out = rem + L.n4 + ((i + 1) & 1) * L.m4; pb.remain_stride = rs;
+        pb.ratio_out = ratioR; pb.ratio_stride = kLevels * nm4;
+        rc = launch_phase<PH_B>(pb, b, var_b(i), st, "approxmatch(B)");
         if (rc) return rc;
         PhaseArgs pc{};
         pc.dbg = dbg_counters ? dbg_counters + 4 + 4 * i : nullptr;
         pc.multiL = multiL; pc.multiR = multiR; pc.first = (i == 0); pc.level = i;
         owner1(pc);
-        pc.w0 = ratioR; pc.w0_stride = kLevels * nm; pc.c0 = lc.c[i];
-        pc.w1 = rem + n; pc.w1_stride = nm;
-        pc.remain = rem; pc.remain_stride = nm;
-        pc.ratio_in = ratioL; pc.ratio_stride = kLevels * nm;
+        pc.w0 = ratioR; pc.w0_stride = kLevels * nm4; pc.c0 = lc.c[i];
+        pc.w1 = rem + L.n4 + ((i + 1) & 1) * L.m4; pc.w1_stride = rs;
+        pc.remain = rem; pc.remain_stride = rs;
+        pc.ratio_in = ratioL; pc.ratio_stride = kLevels * nm4;
         if (i + 1 < kLevels) {
             pc.c1 = lc.c[i + 1];
             pc.cut2 = cut_of(i + 1);  // the coarser of the two levels decides what is exactly zero
-            pc.ratio_out = lv + (size_t)(i + 1) * nm;
-            rc = launch_phase<PH_CA>(pc, b, cull_at(i + 1), st, "approxmatch(CA)");
+            pc.ratio_out = lv + (size_t)(i + 1) * nm4;
+            rc = launch_phase<PH_CA>(pc, b, var_ca(i), st, "approxmatch(CA)");
         } else {
             pc.cut2 = cut_of(i);
-            rc = launch_phase<PH_C>(pc, b, cull_at(i), st, "approxmatch(C)");
+            rc = launch_phase<PH_C>(pc, b, var_ca(i), st, "approxmatch(C)");
         }
         if (rc) return rc;
     }
@@ -1173,12 +1424,14 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, dbg_counters, sizeof h, hipMemcpyDeviceToHost);
         std::fprintf(stderr, "[pcc dbg] A: %d/%d skipped;", h[1], h[0]);
-        for (int i = 0; i < 4; i++) std::fprintf(stderr, " B%d %d/%d CA%d %d/%d;", i, h[3 + 4 * i], h[2 + 4 * i], i, h[5 + 4 * i], h[4 + 4 * i]);
-        std::fprintf(stderr, "\n");
+        for (int i = 0; i < kLevels; i++) std::fprintf(stderr, " B%d %d/%d CA%d %d/%d;", i, h[3 + 4 * i], h[2 + 4 * i], i, h[5 + 4 * i], h[4 + 4 * i]);
+        std::fprintf(stderr, " | COWN stamps (x10ns): scan %d stage-issued %d staged %d loop %d reduced %d ; first start->last dead exit %u, ->last live end %u\n",
+                     h[40], h[41], h[42], h[43], h[44], (unsigned)h[49] - (unsigned)h[48], (unsigned)h[50] - (unsigned)h[48]);
         (void)hipMemset(dbg_counters, 0, sizeof h);
+        (void)hipMemset(dbg_counters + 48, 0xff, sizeof(int));
     }
-    hipLaunchKernelGGL(am_unpermute_kernel, dim3(pcc::ceil_div(n + m, 256), b), dim3(256), 0, st, n, m, lv, rem, rank1, rank2,
-                       lv_orig, temp);
+    hipLaunchKernelGGL(am_unpermute_kernel, dim3(pcc::ceil_div(n + m, 256), b), dim3(256), 0, st, n, m, L.n4, L.m4, lv, rem,
+                       rank1, rank2, lv_orig, temp);
     rc = pcc::check_launch("approxmatch(unpermute)");
     if (rc) return rc;
     const dim3 grid(pcc::ceil_div(n, kMatKT), pcc::ceil_div(m, kMatLT), b);
