@@ -89,7 +89,6 @@ struct PhaseArgs {
     float *ratio_out;                  // A: ratioL_0 ; B: ratioR_i ; CA: ratioL_{i+1}
     long long ratio_stride;            // per-sample stride of the level arrays
     int *dbg;                          // optional [2] counters: blocks visited / skipped (debug builds of the host)
-    int *dbg_stamp;                    // optional [8] in-kernel timestamps
 };
 
 // Work-skipping variants of a phase launch.  All of them only drop terms that are EXACTLY zero:
@@ -151,12 +150,6 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     const float *W1 = (NW == 2) ? a.w1 + (size_t)smp * a.w1_stride : nullptr;
 
     // ---- which owners does this workgroup hold? ----
-    unsigned long long stamp0 = 0;
-    if (COWN && a.dbg_stamp) {
-        stamp0 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0) atomicMin(reinterpret_cast<unsigned *>(&a.dbg_stamp[8]), (unsigned)stamp0);
-    }
-#define PCC_STAMP(k) do { if (COWN && a.dbg_stamp && blockIdx.x == 0 && tid == 0) a.dbg_stamp[(k)] = (int)(__builtin_amdgcn_s_memrealtime() - stamp0); } while (0)
     int n_valid = min(TQ, a.n_own - tile * TQ);  // owners of this tile (sorted positions tile*TQ ...)
     if (COWN) {
         // live owners (remain != 0) of the sample, in order; this workgroup takes the tile-th group of TQ.
@@ -229,13 +222,9 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
             atomicAdd(&a.dbg[1], a.n_own - total);
         }
         n_valid = min(TQ, total - lo);
-        if (n_valid <= 0 || a.level < 0) {
-            if (a.dbg_stamp && tid == 0) atomicMax(reinterpret_cast<unsigned *>(&a.dbg_stamp[9]), (unsigned)__builtin_amdgcn_s_memrealtime());
-            return;  // wave-uniform: nothing live in this tile
-        }
+        if (n_valid <= 0) return;  // wave-uniform: nothing live in this tile
         __syncthreads();
     }
-    PCC_STAMP(0);
     int own_e = -1;  // sorted position of the owner this THREAD finishes in the epilogue
     if (tid < TQ && tid < n_valid) own_e = COWN ? own_idx[tid] : tile * TQ + tid;
 
@@ -339,14 +328,12 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
                 if (NW == 2) dst4[4 * (CH / 4) + i] = v1;
             }
         }
-        PCC_STAMP(1);
         const int nblk = (ngroups + 3) / 4;  // blocks of 16 candidates (4 groups)
         if (CULL) {
             const float *cb = a.cand_box + ((size_t)smp * a.cand_nb + q0 / kBox) * 8;
             for (int i = tid; i < nblk * 8; i += T) lds_bb[i] = cb[i];
         }
         __syncthreads();
-        PCC_STAMP(2);
         // blocks are dealt round-robin to the S waves: a contiguous slice of the Hilbert order is one compact
         // region, so contiguous slices would make culling all-or-nothing per wave and leave the workgroup
         // waiting for its nearest slice
@@ -403,15 +390,12 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
             }
         }
     }
-    PCC_STAMP(3);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         red[0][w][r * 64 + lane] = s0[r];
         if (NW == 2) red[1][w][r * 64 + lane] = s1[r];
     }
     __syncthreads();
-    PCC_STAMP(4);
-    if (COWN && a.dbg_stamp && tid == 0) atomicMax(reinterpret_cast<unsigned *>(&a.dbg_stamp[10]), (unsigned)__builtin_amdgcn_s_memrealtime());
     if (own_e < 0) return;
     {
         const int e = tid;
@@ -993,7 +977,7 @@ __global__ __launch_bounds__(256) void am_col_kernel(int n, int m, int rs, const
 // Partials are combined in a fixed order by reduce_splits_kernel / the slab loop: deterministic.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kGradRT = 64;     // rows per workgroup (16 per wave)
-constexpr int kGradSlab = 2048;  // columns per slab = 8 steps of 256
+constexpr int kGradSlab = 1024;  // columns per slab = 4 steps of 256 (48 column-sum registers per lane; 2048 -> 175 us, 1024 -> 129 us, 512 -> 134 us at B=32,N=2048)
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void am_grad_fused_kernel(int n, int m, int row_tiles,
@@ -1177,7 +1161,7 @@ int launch_phase_rs(PhaseArgs a, int b, int var, hipStream_t st, const char *wha
     const long long grid = (long long)b * a.tiles;
     if (grid > 0x7fffffffLL) return pcc::invalid("approxmatch: grid too large");
     {
-        pcc::ProfScope prof(phase_name<MODE>(a.level < 0 ? 8 : a.level), st);
+        pcc::ProfScope prof(phase_name<MODE>(a.level), st);
         const dim3 g((unsigned)grid), blk(64 * S);
         // only the combinations the schedule uses are instantiated
         if (var == V_CULL) hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, V_CULL>), g, blk, 0, st, a);
@@ -1376,7 +1360,6 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         const char *e = std::getenv("PCC_AM_DEBUG");
         if (e && e[0] == '1' && hipMalloc(reinterpret_cast<void **>(&p), 64 * sizeof(int)) == hipSuccess)
             (void)hipMemset(p, 0, 64 * sizeof(int));
-        if (p) (void)hipMemset(p + 48, 0xff, sizeof(int));
         return p;
     }();
     PhaseArgs a{};
@@ -1391,9 +1374,7 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         float *ratioL = lv + (size_t)i * nm4, *ratioR = ratioL + L.n4;
         PhaseArgs pb{};
         pb.dbg = dbg_counters ? dbg_counters + 2 + 4 * i : nullptr;
-        pb.dbg_stamp = (dbg_counters && i == 8) ? dbg_counters + 40 : nullptr;
         pb.multiL = multiL; pb.multiR = multiR; pb.first = (i == 0); pb.level = i;
-        if (std::getenv("PCC_AM_DBGRET") && i >= 3) pb.level = -1;
         owner2(pb);
         pb.w0 = ratioL; pb.w0_stride = kLevels * nm4; pb.c0 = lc.c[i]; pb.cut2 = cut_of(i);
         pb.remain = rem + L.n4 + (i & 1) * L.m4; pb.remain_out = rem + L.n4 + ((i + 1) & 1) * L.m4; pb.remain_stride = rs;
@@ -1425,10 +1406,8 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         (void)hipMemcpy(h, dbg_counters, sizeof h, hipMemcpyDeviceToHost);
         std::fprintf(stderr, "[pcc dbg] A: %d/%d skipped;", h[1], h[0]);
         for (int i = 0; i < kLevels; i++) std::fprintf(stderr, " B%d %d/%d CA%d %d/%d;", i, h[3 + 4 * i], h[2 + 4 * i], i, h[5 + 4 * i], h[4 + 4 * i]);
-        std::fprintf(stderr, " | COWN stamps (x10ns): scan %d stage-issued %d staged %d loop %d reduced %d ; first start->last dead exit %u, ->last live end %u\n",
-                     h[40], h[41], h[42], h[43], h[44], (unsigned)h[49] - (unsigned)h[48], (unsigned)h[50] - (unsigned)h[48]);
+        std::fprintf(stderr, "\n");
         (void)hipMemset(dbg_counters, 0, sizeof h);
-        (void)hipMemset(dbg_counters + 48, 0xff, sizeof(int));
     }
     hipLaunchKernelGGL(am_unpermute_kernel, dim3(pcc::ceil_div(n + m, 256), b), dim3(256), 0, st, n, m, L.n4, L.m4, lv, rem,
                        rank1, rank2, lv_orig, temp);
