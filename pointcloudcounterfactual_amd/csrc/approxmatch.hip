@@ -122,8 +122,38 @@ __device__ __forceinline__ int compact_pos(bool flag, int w, int lane, int *wave
     return before + lane_off;
 }
 
-template <int MODE, int R, int S, int CH, int VAR>
-__global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
+// Loads / stores of the vectors that workgroups of one sample hand to each other between passes (ratioL, ratioR,
+// remainR).  In the multi-launch schedule the kernel boundary orders them; inside the persistent kernel they are
+// agent-scope (sc1, write-through / L1-bypassing) accesses behind the sample barrier (cdna guide, Guideline 16).
+template <bool PERSIST>
+__device__ __forceinline__ float xld(const float *p) {
+    if (PERSIST) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool PERSIST>
+__device__ __forceinline__ float4 xld4(const float *p) {  // p is 16-byte aligned
+    if (PERSIST) return make_float4(xld<true>(p), xld<true>(p + 1), xld<true>(p + 2), xld<true>(p + 3));
+    return *reinterpret_cast<const float4 *>(p);
+}
+template <bool PERSIST>
+__device__ __forceinline__ void xst(float *p, float v) {
+    if (PERSIST) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+// LDS footprint of one phase (floats / ints), shared by the per-launch kernels and the persistent kernel
+template <int NW, int R, int S, int CH>
+struct PhaseLds {
+    static constexpr int kC = (3 + NW) * CH;          // x | y | z | w0 | (w1)
+    static constexpr int kBB = (CH / kBox) * 8;       // candidate block boxes
+    static constexpr int kRed = NW * S * 64 * R;      // partial sums [NW][S][TQ]
+    static constexpr int kOwn = 64 * R;               // live-owner tile (ints)
+    static constexpr int kWave = S;                   // (ints)
+    static constexpr int floats = kC + kBB + kRed + kOwn + kWave + 4;
+};
+
+template <int MODE, int R, int S, int CH, int VAR, bool PERSIST>
+__device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int tile, float *smem) {
     constexpr int T = 64 * S;
     constexpr int TQ = 64 * R;
     constexpr int NW = (MODE == PH_CA) ? 2 : 1;
@@ -131,19 +161,16 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     constexpr bool CULL = VAR == V_CULL, CCAND = VAR == V_CCAND, COWN = VAR == V_COWN;
     static_assert(!(CCAND && W0_CONST), "pass A of the first level has constant weights");
     static_assert(TQ <= T, "one epilogue owner per thread");
-    __shared__ __attribute__((aligned(16))) float lds_c[(3 + NW) * CH];  // x | y | z | w0 | (w1)
-    __shared__ __attribute__((aligned(16))) float lds_bb[CULL ? (CH / kBox) * 8 : 8];
-    __shared__ float red[NW][S][TQ];
-    __shared__ int own_idx[COWN ? TQ : 1];
-    __shared__ int wave_cnt[S];
+    using L = PhaseLds<2, R, S, CH>;  // offsets do not depend on NW so that every phase sees the same carve
+    float *lds_c = smem;                               // x | y | z | w0 | (w1)
+    float *lds_bb = smem + L::kC;
+    float *red = lds_bb + L::kBB;                      // [NW][S][TQ]
+    int *own_idx = reinterpret_cast<int *>(red + L::kRed);
+    int *wave_cnt = own_idx + L::kOwn;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // V_COWN packs the live owners into the low tiles: dispatch those first (tile-major order), so the workgroups
-    // that have nothing to do and exit after the scan are not in front of the ones that carry the launch
-    const int smp = COWN ? (int)(blockIdx.x % a.batch) : (int)(blockIdx.x / a.tiles);
-    const int tile = COWN ? (int)(blockIdx.x / a.batch) : (int)(blockIdx.x - smp * a.tiles);
     const float *O = a.own_soa + (size_t)smp * 3 * a.own_n4;
     const float *C = a.cand_soa + (size_t)smp * 3 * a.cand_n4;
     const float *W0 = W0_CONST ? nullptr : a.w0 + (size_t)smp * a.w0_stride;
@@ -168,13 +195,13 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
 #pragma unroll
             for (int v = 0; v < V4; v++) {
                 rv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (beg + 4 * v < end) rv[v] = *reinterpret_cast<const float4 *>(rem + beg + 4 * v);
+                if (beg + 4 * v < end) rv[v] = xld4<PERSIST>(rem + beg + 4 * v);
             }
 #pragma unroll
             for (int v = 0; v < V4; v++)
                 mine += (rv[v].x != 0.f) + (rv[v].y != 0.f) + (rv[v].z != 0.f) + (rv[v].w != 0.f);
         } else {
-            for (int i = beg; i < end; i++) mine += rem[i] != 0.f ? 1 : 0;
+            for (int i = beg; i < end; i++) mine += xld<PERSIST>(rem + i) != 0.f ? 1 : 0;
         }
         // exclusive scan of `mine` over the workgroup: wave scan + S-entry LDS scan
         int incl = mine;
@@ -200,7 +227,7 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
             } else if (tile == 0 && i < a.n_own) {
                 // an exhausted owner keeps remainR = 0 (and ratioR = 0 from the zero-filled level array); the
                 // first workgroup of the sample carries the zero over into the output buffer
-                a.remain_out[(size_t)smp * a.remain_stride + i] = 0.f;
+                xst<PERSIST>(&a.remain_out[(size_t)smp * a.remain_stride + i], 0.f);
             }
         };
         if (fast) {
@@ -215,7 +242,7 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
                 }
             }
         } else {
-            for (int i = beg; i < end; i++) place(i, rem[i] != 0.f);
+            for (int i = beg; i < end; i++) place(i, xld<PERSIST>(rem + i) != 0.f);
         }
         if (a.dbg && tile == 0 && tid == 0) {
             atomicAdd(&a.dbg[0], a.n_own);
@@ -257,8 +284,8 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     // operands of the epilogue do not depend on the pair loop: fetch them now, behind the staging traffic
     float pre_rem = 0.f, pre_ratio = 0.f;
     if (own_e >= 0) {
-        if (MODE != PH_A && !a.first) pre_rem = a.remain[(size_t)smp * a.remain_stride + own_e];
-        if (MODE == PH_CA || MODE == PH_C) pre_ratio = a.ratio_in[(size_t)smp * a.ratio_stride + own_e];
+        if (MODE != PH_A && !a.first) pre_rem = xld<PERSIST>(&a.remain[(size_t)smp * a.remain_stride + own_e]);
+        if (MODE == PH_CA || MODE == PH_C) pre_ratio = xld<PERSIST>(&a.ratio_in[(size_t)smp * a.ratio_stride + own_e]);
     }
     const float4 *X4 = reinterpret_cast<const float4 *>(lds_c);
     const float4 *Y4 = X4 + CH / 4;
@@ -278,8 +305,8 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
             for (int base = 0; base < cnt; base += T) {
                 const int i = base + tid;
                 const bool in = i < cnt;
-                const float v0 = in ? W0[q0 + i] : 0.f;
-                const float v1 = (NW == 2 && in) ? W1[q0 + i] : 0.f;
+                const float v0 = in ? xld<PERSIST>(W0 + q0 + i) : 0.f;
+                const float v1 = (NW == 2 && in) ? xld<PERSIST>(W1 + q0 + i) : 0.f;
                 const bool flag = v0 != 0.f || v1 != 0.f;
                 const float vx = in ? C[q0 + i] : 0.f;
                 const float vy = in ? C[(size_t)a.cand_n4 + q0 + i] : 0.f;
@@ -308,13 +335,13 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
             const float4 *sx = reinterpret_cast<const float4 *>(C + q0);
             const float4 *sy = reinterpret_cast<const float4 *>(C + (size_t)a.cand_n4 + q0);
             const float4 *sz = reinterpret_cast<const float4 *>(C + (size_t)2 * a.cand_n4 + q0);
-            const float4 *sw0 = W0_CONST ? nullptr : reinterpret_cast<const float4 *>(W0 + q0);
-            const float4 *sw1 = NW == 2 ? reinterpret_cast<const float4 *>(W1 + q0) : nullptr;
+            const float *sw0 = W0_CONST ? nullptr : W0 + q0;
+            const float *sw1 = NW == 2 ? W1 + q0 : nullptr;
             for (int i = tid; i < ngroups; i += T) {
                 const float4 vx = sx[i], vy = sy[i], vz = sz[i];
                 float4 v0 = make_float4(a.w0c, a.w0c, a.w0c, a.w0c), v1 = v0;
-                if (!W0_CONST) v0 = sw0[i];
-                if (NW == 2) v1 = sw1[i];
+                if (!W0_CONST) v0 = xld4<PERSIST>(sw0 + 4 * i);
+                if (NW == 2) v1 = xld4<PERSIST>(sw1 + 4 * i);
                 if (W0_CONST && i * 4 + 3 >= cnt) {  // padded candidates must weigh 0
                     v0.x = i * 4 + 0 < cnt ? v0.x : 0.f;
                     v0.y = i * 4 + 1 < cnt ? v0.y : 0.f;
@@ -392,42 +419,54 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        red[0][w][r * 64 + lane] = s0[r];
-        if (NW == 2) red[1][w][r * 64 + lane] = s1[r];
+        red[(0 * S + w) * TQ + r * 64 + lane] = s0[r];
+        if (NW == 2) red[(1 * S + w) * TQ + r * 64 + lane] = s1[r];
     }
     __syncthreads();
     if (own_e < 0) return;
     {
         const int e = tid;
         const int o = own_e;
-        float t0 = red[0][0][e], t1 = 0.f;
-        if (NW == 2) t1 = red[1][0][e];
+        float t0 = red[e], t1 = 0.f;
+        if (NW == 2) t1 = red[(1 * S) * TQ + e];
 #pragma unroll
         for (int s = 1; s < S; s++) {
-            t0 += red[0][s][e];
-            if (NW == 2) t1 += red[1][s][e];
+            t0 += red[(0 * S + s) * TQ + e];
+            if (NW == 2) t1 += red[(1 * S + s) * TQ + e];
         }
         if (MODE == PH_A) {
             // ratioL[k] = remainL[k] / (1e-9 + sum)            approxmatch.cu:37,61 (remainL == multiL)
-            a.ratio_out[(size_t)smp * a.ratio_stride + o] = a.multiL / (1e-9f + t0);
+            xst<PERSIST>(&a.ratio_out[(size_t)smp * a.ratio_stride + o], a.multiL / (1e-9f + t0));
         } else if (MODE == PH_B) {
             // approxmatch.cu:106-109
             const float rR = a.first ? a.multiR : pre_rem;
             const float sumr = t0 * rR;
             const float consumption = __builtin_fminf(rR / (sumr + 1e-9f), 1.0f);
-            a.ratio_out[(size_t)smp * a.ratio_stride + o] = consumption * rR;
-            a.remain_out[(size_t)smp * a.remain_stride + o] = __builtin_fmaxf(0.0f, rR - sumr);
+            xst<PERSIST>(&a.ratio_out[(size_t)smp * a.ratio_stride + o], consumption * rR);
+            xst<PERSIST>(&a.remain_out[(size_t)smp * a.remain_stride + o], __builtin_fmaxf(0.0f, rR - sumr));
         } else {
             // pass C: suml = sum_l e*ratioL[k]*ratioR[l] ; remainL = max(0, remainL - suml)   :154-162
             float *rem = a.remain + (size_t)smp * a.remain_stride + o;
             const float rl = pre_ratio;
             const float rL = a.first ? a.multiL : pre_rem;
             const float left = __builtin_fmaxf(0.0f, rL - rl * t0);
-            *rem = left;
+            xst<PERSIST>(rem, left);
             // pass A of the next level: ratioL' = remainL / (1e-9 + sum_l e'*remainR[l])       :37,61
-            if (MODE == PH_CA) a.ratio_out[(size_t)smp * a.ratio_stride + o] = left / (1e-9f + t1);
+            if (MODE == PH_CA) xst<PERSIST>(&a.ratio_out[(size_t)smp * a.ratio_stride + o], left / (1e-9f + t1));
         }
     }
+}
+
+
+template <int MODE, int R, int S, int CH, int VAR>
+__global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[PhaseLds<2, R, S, CH>::floats];
+    // V_COWN packs the live owners into the low tiles: dispatch those first (tile-major order), so the workgroups
+    // that have nothing to do and exit after the scan are not in front of the ones that carry the launch
+    constexpr bool COWN = VAR == V_COWN;
+    const int smp = COWN ? (int)(blockIdx.x % a.batch) : (int)(blockIdx.x / a.tiles);
+    const int tile = COWN ? (int)(blockIdx.x / a.batch) : (int)(blockIdx.x - smp * a.tiles);
+    am_phase_body<MODE, R, S, CH, VAR, false>(a, smp, tile, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -94,7 +94,8 @@ def test_nn_distance_autograd_matches_torch(cuda):
     np.testing.assert_allclose(t2.grad.cpu().numpy(), u2.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
 
 
-AM_SHAPES = [(1, 1, 1), (2, 3, 5), (2, 64, 64), (2, 257, 130), (2, 128, 256), (1, 513, 512), (2, 1024, 1024)]
+AM_SHAPES = [(1, 1, 1), (2, 3, 5), (2, 64, 64), (2, 257, 130), (2, 128, 256), (1, 513, 512), (2, 1024, 1024),
+             (1, 2100, 2300), (1, 4099, 100), (2, 70, 2050)]  # the last three span several 2048-candidate chunks
 
 
 @pytest.mark.parametrize('b,n,m', AM_SHAPES)
