@@ -102,6 +102,84 @@ struct PhaseArgs {
 //           are zero-filled beforehand) and workgroups beyond the live count exit.
 enum Var { V_PLAIN = 0, V_CULL = 1, V_CCAND = 2, V_COWN = 3 };
 
+// Everything a pass needs is derived from this small description of one approxmatch call: the same function
+// builds the arguments of pass p for the per-launch schedule (host) and inside the persistent kernel (device).
+//   p = 0: pass A of level 0;  p = 1 + 2i: pass B of level i;  p = 2 + 2i: pass C of level i fused with pass A of
+//   level i+1 (plain pass C for the last level).
+struct Sched {
+    int n, m, n4, m4, nb1, nb2, nb64_1, nb64_2;
+    const float *soa1, *soa2, *box1, *box2, *box64_1, *box64_2;
+    float *rem, *lv;               // sorted space: remain row = remainL(n4) | remainR ping(m4) | pong(m4); level rows
+    float multiL, multiR, cut_scale;
+    int skip;                      // work-skipping variants enabled
+    LevelConsts lc;
+    int *dbg;
+    int dbg_counts;                // 1: count visited / skipped blocks (slow: one atomic per block)
+};
+
+__host__ __device__ inline int sched_phases() { return 2 * kLevels + 1; }
+
+__host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mode_out, int *var_out) {
+    const long long nm4 = (long long)sc.n4 + sc.m4;
+    const long long rs = (long long)sc.n4 + 2LL * sc.m4;
+    PhaseArgs a{};
+    a.multiL = sc.multiL;
+    a.multiR = sc.multiR;
+    const bool set1_owns = (p == 0) || (p % 2 == 0);
+    if (set1_owns) {  // owners = set1, candidates = set2
+        a.n_own = sc.n; a.n_cand = sc.m; a.own_n4 = sc.n4; a.cand_n4 = sc.m4; a.own_nb = sc.nb1; a.cand_nb = sc.nb2;
+        a.own_soa = sc.soa1; a.cand_soa = sc.soa2; a.own_box = sc.box64_1; a.own_nb64 = sc.nb64_1; a.cand_box = sc.box2;
+    } else {          // owners = set2, candidates = set1
+        a.n_own = sc.m; a.n_cand = sc.n; a.own_n4 = sc.m4; a.cand_n4 = sc.n4; a.own_nb = sc.nb2; a.cand_nb = sc.nb1;
+        a.own_soa = sc.soa2; a.cand_soa = sc.soa1; a.own_box = sc.box64_2; a.own_nb64 = sc.nb64_2; a.cand_box = sc.box1;
+    }
+    int mode, var;
+    if (p == 0) {
+        mode = PH_A;
+        var = sc.skip ? V_CULL : V_PLAIN;
+        a.level = 0;
+        a.w0 = nullptr; a.w0c = sc.multiR; a.c0 = sc.lc.c[0]; a.first = 1;
+        a.cut2 = sc.cut_scale * kZeroExp / -sc.lc.c[0];
+        a.ratio_out = sc.lv; a.ratio_stride = kLevels * nm4;
+        a.dbg = sc.dbg_counts ? sc.dbg : nullptr;
+    } else {
+        const int i = (p - 1) / 2;
+        float *ratioL = sc.lv + (size_t)i * nm4, *ratioR = ratioL + sc.n4;
+        a.level = i;
+        a.first = (i == 0);
+        a.c0 = sc.lc.c[i];
+        if (p % 2 == 1) {  // pass B of level i
+            mode = PH_B;
+            // box culling while the zero radius is small against the cloud (levels 0-2), live-owner compaction after
+            var = !sc.skip ? V_PLAIN : i <= 2 ? V_CULL : V_COWN;
+            a.w0 = ratioL; a.w0_stride = kLevels * nm4;
+            a.cut2 = sc.cut_scale * kZeroExp / -sc.lc.c[i];
+            a.remain = sc.rem + sc.n4 + (i & 1) * sc.m4;
+            a.remain_out = sc.rem + sc.n4 + ((i + 1) & 1) * sc.m4;
+            a.remain_stride = rs;
+            a.ratio_out = ratioR; a.ratio_stride = kLevels * nm4;
+            a.dbg = sc.dbg_counts ? sc.dbg + 2 + 4 * i : nullptr;
+        } else {           // pass C of level i (+ pass A of level i+1)
+            mode = i + 1 < kLevels ? PH_CA : PH_C;
+            var = !sc.skip ? V_PLAIN : i <= 1 ? V_CULL : V_CCAND;  // the cull radius is the one of level i+1
+            a.w0 = ratioR; a.w0_stride = kLevels * nm4;
+            a.w1 = sc.rem + sc.n4 + ((i + 1) & 1) * sc.m4; a.w1_stride = rs;
+            a.remain = sc.rem; a.remain_stride = rs;
+            a.ratio_in = ratioL; a.ratio_stride = kLevels * nm4;
+            const int lc_i = i + 1 < kLevels ? i + 1 : i;
+            a.cut2 = sc.cut_scale * kZeroExp / -sc.lc.c[lc_i];  // the coarser of the two levels decides what is 0
+            if (i + 1 < kLevels) {
+                a.c1 = sc.lc.c[i + 1];
+                a.ratio_out = sc.lv + (size_t)(i + 1) * nm4;
+            }
+            a.dbg = sc.dbg_counts ? sc.dbg + 4 + 4 * i : nullptr;
+        }
+    }
+    *mode_out = mode;
+    *var_out = var;
+    return a;
+}
+
 // order-preserving compaction step shared by V_CCAND / V_COWN: position of this thread's element among the
 // flagged elements of the whole workgroup round (wave ballots + an S-entry LDS scan)
 template <int S>
@@ -177,6 +255,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     const float *W1 = (NW == 2) ? a.w1 + (size_t)smp * a.w1_stride : nullptr;
 
     // ---- which owners does this workgroup hold? ----
+    if (!COWN && tile * TQ >= a.n_own) return;         // (persistent kernel: the two clouds may need different tile counts)
     int n_valid = min(TQ, a.n_own - tile * TQ);  // owners of this tile (sorted positions tile*TQ ...)
     if (COWN) {
         // live owners (remain != 0) of the sample, in order; this workgroup takes the tile-th group of TQ.
@@ -300,27 +379,50 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         int ngroups = (cnt + 3) / 4;
         if (q0) __syncthreads();
         if (CCAND) {
-            // stage only the candidates that can contribute (some weight != 0), order preserved
-            int running = 0;
-            for (int base = 0; base < cnt; base += T) {
-                const int i = base + tid;
+            // stage only the candidates that can contribute (some weight != 0), order preserved.  Every thread
+            // owns a contiguous run of PER candidates (all their loads in flight together), one block scan places them.
+            constexpr int PER = (CH + T - 1) / T;
+            const int beg = tid * PER;
+            float cv0[PER], cv1[PER], cvx[PER], cvy[PER], cvz[PER];
+            int mine = 0;
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                const int i = beg + j;
                 const bool in = i < cnt;
-                const float v0 = in ? xld<PERSIST>(W0 + q0 + i) : 0.f;
-                const float v1 = (NW == 2 && in) ? xld<PERSIST>(W1 + q0 + i) : 0.f;
-                const bool flag = v0 != 0.f || v1 != 0.f;
-                const float vx = in ? C[q0 + i] : 0.f;
-                const float vy = in ? C[(size_t)a.cand_n4 + q0 + i] : 0.f;
-                const float vz = in ? C[(size_t)2 * a.cand_n4 + q0 + i] : 0.f;
-                int round_total;
-                const int pos = running + compact_pos<S>(flag, w, lane, wave_cnt, round_total);
-                if (flag) {
-                    lds_c[pos] = vx;
-                    lds_c[CH + pos] = vy;
-                    lds_c[2 * CH + pos] = vz;
-                    lds_c[3 * CH + pos] = v0;
-                    if (NW == 2) lds_c[4 * CH + pos] = v1;
+                cv0[j] = in ? xld<PERSIST>(W0 + q0 + i) : 0.f;
+                cv1[j] = (NW == 2 && in) ? xld<PERSIST>(W1 + q0 + i) : 0.f;
+                cvx[j] = in ? C[q0 + i] : 0.f;
+                cvy[j] = in ? C[(size_t)a.cand_n4 + q0 + i] : 0.f;
+                cvz[j] = in ? C[(size_t)2 * a.cand_n4 + q0 + i] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < PER; j++) mine += (cv0[j] != 0.f || cv1[j] != 0.f) ? 1 : 0;
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off, 64);
+                incl += lane >= off ? v : 0;
+            }
+            if (lane == 63) wave_cnt[w] = incl;
+            __syncthreads();
+            int before = 0, running = 0;
+#pragma unroll
+            for (int i = 0; i < S; i++) {
+                const int c = wave_cnt[i];
+                before += i < w ? c : 0;
+                running += c;
+            }
+            int pos = before + incl - mine;
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                if (cv0[j] != 0.f || cv1[j] != 0.f) {
+                    lds_c[pos] = cvx[j];
+                    lds_c[CH + pos] = cvy[j];
+                    lds_c[2 * CH + pos] = cvz[j];
+                    lds_c[3 * CH + pos] = cv0[j];
+                    if (NW == 2) lds_c[4 * CH + pos] = cv1[j];
+                    pos++;
                 }
-                running += round_total;
             }
             ngroups = (running + 3) / 4;
             if (tid < ngroups * 4 - running) {  // zero the tail of the last group
@@ -467,6 +569,71 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     const int smp = COWN ? (int)(blockIdx.x % a.batch) : (int)(blockIdx.x / a.tiles);
     const int tile = COWN ? (int)(blockIdx.x / a.batch) : (int)(blockIdx.x - smp * a.tiles);
     am_phase_body<MODE, R, S, CH, VAR, false>(a, smp, tile, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent schedule (experimental, off by default -- see the measurement note at its launch site): ONE launch runs
+// all 19 passes.  The measured fixed cost of a pass launch (dispatch, prologue latency, drain) is 10.5 us -- a third
+// of the forward once the exact-zero work is skipped.  Here a workgroup keeps
+// its tile for the whole recurrence and the 16 workgroups of a sample meet at a sample-local barrier between passes:
+// the vectors they exchange (ratioL, ratioR, remainR) are stored and loaded with agent-scope (sc1) accesses, every
+// storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup barrier, then one lane bumps the sample's
+// counter and polls it (cdna_hip_programming.md Guideline 16, counter form; no cache-wide fences).  All workgroups
+// must be co-resident: the host launches at most as many as fit (LDS allows two 512-thread workgroups per CU) and
+// splits larger batches into consecutive launches; spins are bounded and raise an error word instead of hanging.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sample_barrier(unsigned *ctr, unsigned target, unsigned *err, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores have left the CU
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 22)) {  // ~1 s: a workgroup of this sample never arrived (not co-resident?)
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int R, int S, int CH>
+__global__ __launch_bounds__(64 * S) void am_persistent_kernel(Sched sc, unsigned *counters, unsigned *err, int tiles,
+                                                                int smp0) {
+    __shared__ __attribute__((aligned(16))) float smem[PhaseLds<2, R, S, CH>::floats];
+    const int smp = smp0 + (int)(blockIdx.x / tiles);
+    const int tile = (int)(blockIdx.x % tiles);
+    const int nph = sched_phases();
+    unsigned long long t0 = sc.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
+    for (int p = 0; p < nph; p++) {
+        int mode, var;
+        const PhaseArgs a = build_phase(sc, p, &mode, &var);
+        if (mode == PH_A) {
+            if (var == V_CULL) am_phase_body<PH_A, R, S, CH, V_CULL, true>(a, smp, tile, smem);
+            else am_phase_body<PH_A, R, S, CH, V_PLAIN, true>(a, smp, tile, smem);
+        } else if (mode == PH_B) {
+            if (var == V_CULL) am_phase_body<PH_B, R, S, CH, V_CULL, true>(a, smp, tile, smem);
+            else if (var == V_COWN) am_phase_body<PH_B, R, S, CH, V_COWN, true>(a, smp, tile, smem);
+            else am_phase_body<PH_B, R, S, CH, V_PLAIN, true>(a, smp, tile, smem);
+        } else if (mode == PH_CA) {
+            if (var == V_CULL) am_phase_body<PH_CA, R, S, CH, V_CULL, true>(a, smp, tile, smem);
+            else if (var == V_CCAND) am_phase_body<PH_CA, R, S, CH, V_CCAND, true>(a, smp, tile, smem);
+            else am_phase_body<PH_CA, R, S, CH, V_PLAIN, true>(a, smp, tile, smem);
+        } else {
+            if (var == V_CCAND) am_phase_body<PH_C, R, S, CH, V_CCAND, true>(a, smp, tile, smem);
+            else am_phase_body<PH_C, R, S, CH, V_PLAIN, true>(a, smp, tile, smem);
+        }
+        unsigned long long t1 = 0;
+        if (sc.dbg && blockIdx.x == 0 && threadIdx.x == 0) t1 = __builtin_amdgcn_s_memrealtime();
+        if (p + 1 < nph) sample_barrier(counters + smp, (unsigned)tiles * (unsigned)(p + 1), err, threadIdx.x);
+        if (sc.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
+            const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+            sc.dbg[40 + p] = (int)(((t1 - t0) << 16) | ((t2 - t1) & 0xffff));  // body | barrier, 10 ns units
+            t0 = t2;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -697,7 +864,10 @@ __global__ __launch_bounds__(256) void am_unpermute_kernel(int n, int m, int n4,
                                                             const float *__restrict__ rem_sorted,
                                                             const int *__restrict__ rank1,
                                                             const int *__restrict__ rank2,
+                                                            const unsigned *__restrict__ err,
                                                             float *__restrict__ lv, float *__restrict__ temp) {
+    // a sample barrier of the persistent kernel timed out: poison the outputs instead of returning garbage
+    const float poison = (err && *err) ? __builtin_nanf("") : 0.f;
     // sorted-space rows are [ratioL (n4) | ratioR (m4)] (16-byte aligned halves); outputs are dense [n | m]
     const int smp = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -709,7 +879,7 @@ __global__ __launch_bounds__(256) void am_unpermute_kernel(int n, int m, int n4,
     float last = 0.f;
 #pragma unroll
     for (int l = 0; l < kLevels; l++) {
-        last = src[(size_t)l * nm4 + s];
+        last = src[(size_t)l * nm4 + s] + poison;
         dst[(size_t)l * nm + i] = last;
     }
     // remain row: remainL (n4) | remainR ping (m4) | pong (m4); the nine passes B leave the final remainR in pong
@@ -1282,7 +1452,7 @@ size_t cost_parts(int n, int m) { return (size_t)pcc::ceil_div(n, kMatKT) * pcc:
 // Workspace carve (bytes, every section 16-byte aligned).
 struct WsLayout {
     int n4, m4, nb1, nb2, nb64_1, nb64_2;
-    size_t soa1, soa2, rank1, rank2, box1, box2, box64_1, box64_2, rem, lv, lv_orig, cpart, total;
+    size_t soa1, soa2, rank1, rank2, box1, box2, box64_1, box64_2, rem, lv, lv_orig, cpart, sync, total;
     WsLayout(int b, int n, int m) {
         auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
         n4 = (n + 3) & ~3;
@@ -1304,6 +1474,7 @@ struct WsLayout {
         lv = o; o = up(o + (size_t)b * kLevels * ((size_t)n4 + m4) * 4);      // sorted space, padded halves
         lv_orig = o; o = up(o + (size_t)b * kLevels * ((size_t)n + m) * 4);
         cpart = o; o = up(o + (size_t)b * cost_parts(n, m) * 4);
+        sync = o; o = up(o + ((size_t)b + 1) * 4);   // per-sample barrier counters + error word (persistent kernel)
         total = o;
     }
 };
@@ -1373,71 +1544,83 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         }
     }
 
-    // A level is worth culling while its zero radius is small against the cloud; beyond level 3 (|c| < 92,
-    // radius > 1.2) nothing can be skipped for unit-ball clouds and the box test would be pure overhead.
     static const float cut_scale = [] {  // debugging aid: PCC_AM_CUTSCALE < 1 skips more than is exact
         const char *e = std::getenv("PCC_AM_CUTSCALE");
         return e ? (float)std::atof(e) : 1.0f;
     }();
-    auto cut_of = [&](int i) { return cut_scale * kZeroExp / -lc.c[i]; };
-    // schedule of the work-skipping variants (see enum Var): box culling while the zero radius is small against the
-    // cloud (levels 0-3: beyond that nothing can be skipped for unit-ball clouds), exhausted-point compaction after
-    auto var_b = [&](int i) { return !cull_enabled() ? V_PLAIN : i <= 2 ? V_CULL : V_COWN; };
-    auto var_ca = [&](int i) { return !cull_enabled() ? V_PLAIN : i <= 1 ? V_CULL : V_CCAND; };  // culls at level i+1
-
-    auto owner1 = [&](PhaseArgs &a) {  // owners = set1, candidates = set2
-        a.n_own = n; a.n_cand = m; a.own_n4 = L.n4; a.cand_n4 = L.m4; a.own_nb = L.nb1; a.cand_nb = L.nb2;
-        a.own_soa = soa1; a.cand_soa = soa2; a.own_box = box64_1; a.own_nb64 = L.nb64_1; a.cand_box = box2;
-    };
-    auto owner2 = [&](PhaseArgs &a) {  // owners = set2, candidates = set1
-        a.n_own = m; a.n_cand = n; a.own_n4 = L.m4; a.cand_n4 = L.n4; a.own_nb = L.nb2; a.cand_nb = L.nb1;
-        a.own_soa = soa2; a.cand_soa = soa1; a.own_box = box64_2; a.own_nb64 = L.nb64_2; a.cand_box = box1;
-    };
-
     static int *dbg_counters = [] {
         int *p = nullptr;
         const char *e = std::getenv("PCC_AM_DEBUG");
-        if (e && e[0] == '1' && hipMalloc(reinterpret_cast<void **>(&p), 64 * sizeof(int)) == hipSuccess)
+        if (e && (e[0] == '1' || e[0] == '2') && hipMalloc(reinterpret_cast<void **>(&p), 64 * sizeof(int)) == hipSuccess)
             (void)hipMemset(p, 0, 64 * sizeof(int));
         return p;
     }();
-    PhaseArgs a{};
-    a.dbg = dbg_counters;
-    a.multiL = multiL; a.multiR = multiR;
-    owner1(a);
-    a.w0 = nullptr; a.w0c = multiR; a.c0 = lc.c[0]; a.first = 1; a.cut2 = cut_of(0);
-    a.ratio_out = lv; a.ratio_stride = kLevels * nm4;
-    rc = launch_phase<PH_A>(a, b, cull_enabled() ? V_CULL : V_PLAIN, st, "approxmatch(A)");
-    if (rc) return rc;
-    for (int i = 0; i < kLevels; i++) {
-        float *ratioL = lv + (size_t)i * nm4, *ratioR = ratioL + L.n4;
-        PhaseArgs pb{};
-        pb.dbg = dbg_counters ? dbg_counters + 2 + 4 * i : nullptr;
-        pb.multiL = multiL; pb.multiR = multiR; pb.first = (i == 0); pb.level = i;
-        owner2(pb);
-        pb.w0 = ratioL; pb.w0_stride = kLevels * nm4; pb.c0 = lc.c[i]; pb.cut2 = cut_of(i);
-        pb.remain = rem + L.n4 + (i & 1) * L.m4; pb.remain_out = rem + L.n4 + ((i + 1) & 1) * L.m4; pb.remain_stride = rs;
-        pb.ratio_out = ratioR; pb.ratio_stride = kLevels * nm4;
-        rc = launch_phase<PH_B>(pb, b, var_b(i), st, "approxmatch(B)");
-        if (rc) return rc;
-        PhaseArgs pc{};
-        pc.dbg = dbg_counters ? dbg_counters + 4 + 4 * i : nullptr;
-        pc.multiL = multiL; pc.multiR = multiR; pc.first = (i == 0); pc.level = i;
-        owner1(pc);
-        pc.w0 = ratioR; pc.w0_stride = kLevels * nm4; pc.c0 = lc.c[i];
-        pc.w1 = rem + L.n4 + ((i + 1) & 1) * L.m4; pc.w1_stride = rs;
-        pc.remain = rem; pc.remain_stride = rs;
-        pc.ratio_in = ratioL; pc.ratio_stride = kLevels * nm4;
-        if (i + 1 < kLevels) {
-            pc.c1 = lc.c[i + 1];
-            pc.cut2 = cut_of(i + 1);  // the coarser of the two levels decides what is exactly zero
-            pc.ratio_out = lv + (size_t)(i + 1) * nm4;
-            rc = launch_phase<PH_CA>(pc, b, var_ca(i), st, "approxmatch(CA)");
-        } else {
-            pc.cut2 = cut_of(i);
-            rc = launch_phase<PH_C>(pc, b, var_ca(i), st, "approxmatch(C)");
+    static const int dbg_counts = [] {
+        const char *e = std::getenv("PCC_AM_DEBUG");
+        return (e && e[0] == '1') ? 1 : 0;
+    }();
+    Sched sc{};
+    sc.n = n; sc.m = m; sc.n4 = L.n4; sc.m4 = L.m4; sc.nb1 = L.nb1; sc.nb2 = L.nb2; sc.nb64_1 = L.nb64_1; sc.nb64_2 = L.nb64_2;
+    sc.soa1 = soa1; sc.soa2 = soa2; sc.box1 = box1; sc.box2 = box2; sc.box64_1 = box64_1; sc.box64_2 = box64_2;
+    sc.rem = rem; sc.lv = lv; sc.multiL = multiL; sc.multiR = multiR; sc.cut_scale = cut_scale;
+    sc.skip = cull_enabled() ? 1 : 0;
+    sc.lc = lc;
+    sc.dbg = dbg_counters;
+    sc.dbg_counts = dbg_counts;
+
+    // Persistent schedule (one launch for the 19 passes) when the whole batch group can be co-resident and fills the
+    // chip; otherwise one launch per pass.
+    constexpr int kPR = 2, kPS = 8;  // workgroup shape of the persistent kernel (128 owners x 8 waves)
+    const int tiles = std::max(pcc::ceil_div(n, 64 * kPR), pcc::ceil_div(m, 64 * kPR));
+    int resident = 0;
+    {
+        static const int per_cu = [] {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, am_persistent_kernel<kPR, kPS, kPhCH>, 64 * kPS, 0) != hipSuccess) nb = 0;
+            return nb;
+        }();
+        static const int cus = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+            return v;
+        }();
+        resident = per_cu * cus;
+    }
+    // Measured on MI355X (B=32, N=2048): the persistent schedule is SLOWER than one launch per pass (0.97 ms vs
+    // 0.60 ms): the sc1 hand-off adds ~2 us of memory-side latency to every staging, the workgroups of a sample
+    // wait 10-18 us per pass for their slowest member, and the workgroups parked at a barrier poll while the live
+    // tiles of the owner-compacted passes still run.  It stays available (PCC_AM_PERSIST=1, parity-tested) as the
+    // starting point for the next attempt; the default is one launch per pass.
+    static const int persist_mode = [] {
+        const char *e = std::getenv("PCC_AM_PERSIST");
+        return e ? std::atoi(e) : 0;
+    }();
+    const int group = resident > 0 ? resident / tiles : 0;  // samples per persistent launch
+    const bool use_persist = persist_mode == 1 && group >= 1;
+    if (use_persist) {
+        unsigned *counters = reinterpret_cast<unsigned *>(base + L.sync);
+        if (hipMemsetAsync(counters, 0, ((size_t)b + 1) * sizeof(unsigned), st) != hipSuccess)
+            return pcc::invalid("approxmatch: memset failed");
+        for (int s0 = 0; s0 < b; s0 += group) {
+            const int gb = std::min(group, b - s0);
+            pcc::ProfScope prof("am_persistent_kernel", st);
+            hipLaunchKernelGGL((am_persistent_kernel<kPR, kPS, kPhCH>), dim3((unsigned)(gb * tiles)), dim3(64 * kPS), 0, st, sc,
+                               counters, counters + b, tiles, s0);
         }
+        rc = pcc::check_launch("approxmatch(persistent)");
         if (rc) return rc;
+    } else {
+        for (int p = 0; p < sched_phases(); p++) {
+            int mode, var;
+            const PhaseArgs a = build_phase(sc, p, &mode, &var);
+            switch (mode) {
+            case PH_A: rc = launch_phase<PH_A>(a, b, var, st, "approxmatch(A)"); break;
+            case PH_B: rc = launch_phase<PH_B>(a, b, var, st, "approxmatch(B)"); break;
+            case PH_CA: rc = launch_phase<PH_CA>(a, b, var, st, "approxmatch(CA)"); break;
+            default: rc = launch_phase<PH_C>(a, b, var, st, "approxmatch(C)"); break;
+            }
+            if (rc) return rc;
+        }
     }
     if (dbg_counters) {
         int h[64];
@@ -1445,11 +1628,13 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         (void)hipMemcpy(h, dbg_counters, sizeof h, hipMemcpyDeviceToHost);
         std::fprintf(stderr, "[pcc dbg] A: %d/%d skipped;", h[1], h[0]);
         for (int i = 0; i < kLevels; i++) std::fprintf(stderr, " B%d %d/%d CA%d %d/%d;", i, h[3 + 4 * i], h[2 + 4 * i], i, h[5 + 4 * i], h[4 + 4 * i]);
+        std::fprintf(stderr, "\n[pcc dbg] persistent block 0, per pass body/barrier x10ns:");
+        for (int q = 0; q < sched_phases(); q++) std::fprintf(stderr, " %d/%d", (unsigned)h[40 + q] >> 16, h[40 + q] & 0xffff);
         std::fprintf(stderr, "\n");
         (void)hipMemset(dbg_counters, 0, sizeof h);
     }
     hipLaunchKernelGGL(am_unpermute_kernel, dim3(pcc::ceil_div(n + m, 256), b), dim3(256), 0, st, n, m, L.n4, L.m4, lv, rem,
-                       rank1, rank2, lv_orig, temp);
+                       rank1, rank2, use_persist ? reinterpret_cast<const unsigned *>(base + L.sync) + b : nullptr, lv_orig, temp);
     rc = pcc::check_launch("approxmatch(unpermute)");
     if (rc) return rc;
     const dim3 grid(pcc::ceil_div(n, kMatKT), pcc::ceil_div(m, kMatLT), b);
