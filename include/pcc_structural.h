@@ -107,6 +107,10 @@ void matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2, co
                    float *grad1, float *grad2, pcc_stream_t stream);
 int pcc_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
                       float *grad1, float *grad2, pcc_stream_t stream);
+/* The same with the upstream gradient folded in: grad1[b] *= grad_cost[b], grad2[b] *= grad_cost[b] -- what the
+ * Python wrapper does with two extra elementwise passes (match_cost.py:41-42).  grad_cost == NULL means 1. */
+int pcc_matchcostgrad_scaled(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                             const float *grad_cost, float *grad1, float *grad2, pcc_stream_t stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -37,6 +37,7 @@ ABI: dict[str, tuple[object, list[object]]] = {
     'pcc_matchcost': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     'matchcostgrad': (None, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcc_matchcostgrad': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_matchcostgrad_scaled': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     # include/pcc_neighbour.h
     'pcc_knn': (_int, [_int, _int, _int, _int, _vp, _vp, _vp]),
     'pcc_gather_neighbours': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp]),

@@ -108,6 +108,25 @@ def MatchCostGrad(set_d: torch.Tensor, set_q: torch.Tensor, match: torch.Tensor)
     return [grad1, grad2]
 
 
+def MatchCostGradScaled(set_d: torch.Tensor, set_q: torch.Tensor, match: torch.Tensor,
+                        grad_cost: torch.Tensor) -> list[torch.Tensor]:
+    """MatchCostGrad with the upstream gradient ``grad_cost[B]`` folded into the reduction (extension): equals
+    ``grad * grad_cost[:, None, None]`` of the reference wrapper (match_cost.py:41-42) without the two extra passes."""
+    b, n, m = _sizes(set_d, set_q)
+    grad1 = torch.empty((b, n, 3), dtype=torch.float32, device=set_d.device)
+    grad2 = torch.empty((b, m, 3), dtype=torch.float32, device=set_d.device)
+    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (match, 'match'), (grad_cost, 'grad_cost')):
+        _check_input(t, name)
+        _f32(t, name)
+    if match.numel() != b * n * m or grad_cost.numel() != b:
+        raise RuntimeError('MatchCostGradScaled: match / grad_cost shapes do not match the clouds')
+    with torch.cuda.device(set_d.device):
+        _lib.check(_L.pcc_matchcostgrad_scaled(b, n, m, set_d.data_ptr(), set_q.data_ptr(), match.data_ptr(),
+                                               grad_cost.data_ptr(), grad1.data_ptr(), grad2.data_ptr(),
+                                               _stream(set_d)), 'MatchCostGradScaled')
+    return [grad1, grad2]
+
+
 def NNDistance(set_d: torch.Tensor, set_q: torch.Tensor) -> list[torch.Tensor]:
     """-> [dist1[B,N] f32, idx1[B,N] i32, dist2[B,M] f32, idx2[B,M] i32]   (structural_loss.cpp:81-100)."""
     b, n, m = _sizes(set_d, set_q)

@@ -1194,7 +1194,8 @@ __global__ __launch_bounds__(256) void am_grad_fused_kernel(int n, int m, int ro
                                                              const float *__restrict__ xyz2,
                                                              const float *__restrict__ match,
                                                              float *__restrict__ part1,  // [b][row_tiles][n][3]
-                                                             float *__restrict__ part2)  // [b][slabs][m][3]
+                                                             float *__restrict__ part2,  // [b][slabs][m][3]
+                                                             const float *__restrict__ scale2)  // applied when part2 IS grad2
 {
     constexpr int STEPS = kGradSlab / 256;
     // set1 slab SoA (24 KiB); after the row loop the same bytes carry one wave's column sums at a time to wave 0
@@ -1274,9 +1275,10 @@ __global__ __launch_bounds__(256) void am_grad_fused_kernel(int n, int m, int ro
         }
         if (lane == 0) {
             float *dst = part2 + (((size_t)smp * gridDim.y + slab) * m + row) * 3;
-            dst[0] = rx;
-            dst[1] = ry;
-            dst[2] = rz;
+            const float sc = scale2 ? scale2[smp] : 1.0f;
+            dst[0] = scale2 ? rx * sc : rx;
+            dst[1] = scale2 ? ry * sc : ry;
+            dst[2] = scale2 ? rz * sc : rz;
         }
     }
     // column partials: waves 1, 2, 3 hand their sums to wave 0 one after the other (fixed order)
@@ -1318,14 +1320,14 @@ __global__ __launch_bounds__(256) void am_grad_fused_kernel(int n, int m, int ro
 
 // grad1[b][i] = sum_s part[b][s][i]  (i over n*3), fixed order.
 __global__ __launch_bounds__(256) void reduce_splits_kernel(int rs, size_t per_sample, const float *__restrict__ part,
-                                                             float *__restrict__ out) {
+                                                             const float *__restrict__ scale, float *__restrict__ out) {
     const int smp = blockIdx.y;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= per_sample) return;
     const float *p = part + (size_t)smp * rs * per_sample + i;
     float s = p[0];
     for (int t = 1; t < rs; t++) s += p[t * per_sample];
-    out[(size_t)smp * per_sample + i] = s;
+    out[(size_t)smp * per_sample + i] = scale ? s * scale[smp] : s;  // optional upstream gradient (match_cost.py:41-42)
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -1751,8 +1753,8 @@ void matchcost(int b, int n, int m, const float *xyz1, const float *xyz2, float 
     (void)pcc_matchcost(b, n, m, xyz1, xyz2, match, out, stream);
 }
 
-int pcc_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *grad1,
-                      float *grad2, pcc_stream_t stream) {
+int pcc_matchcostgrad_scaled(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                             const float *grad_cost, float *grad1, float *grad2, pcc_stream_t stream) {
     pcc::clear_error();
     if (int rc = check_sizes("matchcostgrad: bad size", b, n, m)) return rc;
     if (b == 0) return PCC_OK;
@@ -1774,15 +1776,21 @@ int pcc_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2,
     {
         pcc::ProfScope prof("am_grad_fused_kernel", st);
         const dim3 grid(row_tiles, slabs, b);
-        if (vec) hipLaunchKernelGGL((am_grad_fused_kernel<true>), grid, dim3(256), 0, st, n, m, row_tiles, xyz1, xyz2, match, part1, part2);
-        else hipLaunchKernelGGL((am_grad_fused_kernel<false>), grid, dim3(256), 0, st, n, m, row_tiles, xyz1, xyz2, match, part1, part2);
+        const float *sc2 = slabs > 1 ? nullptr : grad_cost;
+        if (vec) hipLaunchKernelGGL((am_grad_fused_kernel<true>), grid, dim3(256), 0, st, n, m, row_tiles, xyz1, xyz2, match, part1, part2, sc2);
+        else hipLaunchKernelGGL((am_grad_fused_kernel<false>), grid, dim3(256), 0, st, n, m, row_tiles, xyz1, xyz2, match, part1, part2, sc2);
     }
     if (int rc = pcc::check_launch("matchcostgrad(fused)")) return rc;
     const size_t per1 = (size_t)n * 3, per2 = (size_t)m * 3;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((per1 + 255) / 256), b), dim3(256), 0, st, row_tiles, per1, part1, grad1);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((per1 + 255) / 256), b), dim3(256), 0, st, row_tiles, per1, part1, grad_cost, grad1);
     if (slabs > 1)
-        hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((per2 + 255) / 256), b), dim3(256), 0, st, slabs, per2, part2, grad2);
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((per2 + 255) / 256), b), dim3(256), 0, st, slabs, per2, part2, grad_cost, grad2);
     return pcc::check_launch("matchcostgrad(reduce)");
+}
+
+int pcc_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *grad1,
+                      float *grad2, pcc_stream_t stream) {
+    return pcc_matchcostgrad_scaled(b, n, m, xyz1, xyz2, match, nullptr, grad1, grad2, stream);
 }
 
 void matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match, float *grad1,

@@ -61,6 +61,9 @@ class MatchCostFunction(Function):
     def backward(ctx: Any, *grad_outputs: Any) -> tuple[torch.Tensor, torch.Tensor]:
         grad_output = grad_outputs[0]
         set1, set2 = ctx.saved_tensors
+        if MatchCostFunction.fused_forward:  # upstream gradient folded into the reduction of the gradient kernel
+            grad1, grad2 = backend.MatchCostGradScaled(set1, set2, ctx.match, grad_output.contiguous().float())
+            return grad1, grad2
         grad1, grad2 = backend.MatchCostGrad(set1, set2, ctx.match)
         scale = grad_output.unsqueeze(1).unsqueeze(2)
         return grad1 * scale, grad2 * scale

@@ -270,3 +270,46 @@ def test_persistent_schedule_parity(cuda):
     np.testing.assert_allclose(outs[1]['cost'], outs[0]['cost'], rtol=1e-5)
     np.testing.assert_allclose(outs[1]['mass'], outs[0]['mass'], rtol=1e-5)
     np.testing.assert_allclose(outs[1]['rem'], outs[0]['rem'], rtol=0, atol=5e-4)
+
+
+def test_bit_reproducible_run_to_run(cuda):
+    """No float atomics on the forward path and fixed-order two-stage reductions: two runs give the same bits
+    (the reference's unordered atomics do not).  The Chamfer backward accumulates with LDS float atomics and is
+    only reproducible to rounding when three or more neighbours share a target."""
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(31, 8, 2048, 2048)
+    t1, t2 = _dev(a, cuda), _dev(c, cuda)
+    r1 = backend.ApproxMatchCost(t1, t2)
+    n1 = backend.NNDistance(t1, t2)
+    g1 = backend.MatchCostGrad(t1, t2, r1[0])
+    for _ in range(3):
+        r2 = backend.ApproxMatchCost(t1, t2)
+        n2 = backend.NNDistance(t1, t2)
+        g2 = backend.MatchCostGrad(t1, t2, r2[0])
+        assert all(torch.equal(x, y) for x, y in zip(r1, r2))
+        assert all(torch.equal(x, y) for x, y in zip(n1, n2))
+        assert all(torch.equal(x, y) for x, y in zip(g1, g2))
+
+
+def test_match_cost_autograd_fused_vs_reference_sequence(cuda):
+    """match_cost through the fused entry points (pcc_approxmatch_cost, pcc_matchcostgrad_scaled) == the reference's
+    call sequence ApproxMatch -> MatchCost -> MatchCostGrad -> grad * grad_output (match_cost.py:25-42)."""
+    from pointcloudcounterfactual_amd.losses import MatchCostFunction, match_cost
+
+    a, c = pair(23, 3, 700, 512)
+    w = torch.tensor([0.5, -2.0, 3.0], device=cuda)
+    res = []
+    try:
+        for fused in (True, False):
+            MatchCostFunction.fused_forward = fused
+            t1 = _dev(a, cuda).requires_grad_(True)
+            t2 = _dev(c, cuda).requires_grad_(True)
+            cost = match_cost(t1, t2)
+            (cost * w).sum().backward()
+            res.append((cost.detach(), t1.grad, t2.grad))
+    finally:
+        MatchCostFunction.fused_forward = True
+    np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), rtol=1e-5)
+    for k in (1, 2):
+        np.testing.assert_allclose(res[0][k].cpu().numpy(), res[1][k].cpu().numpy(), rtol=1e-6, atol=1e-7)
