@@ -33,6 +33,7 @@ def main() -> None:
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch-per-gpu', type=int, default=32)
     ap.add_argument('--points', type=int, default=2048)
+    ap.add_argument('--unfused', action='store_true', help='compose EdgeConv as the reference does ([B,2C,N,k] tensor)')
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -54,7 +55,7 @@ def main() -> None:
     torch.manual_seed(1234 + 4 + rank)
     _, ref = pair(1234 + 4 + 1000 * rank, args.batch_per_gpu, args.points, args.points, 'recon')
     ref_t = torch.from_numpy(ref).to(dev)
-    model = harness.VQAutoencoder(n_points=args.points).to(dev)
+    model = harness.VQAutoencoder(n_points=args.points, fused=not args.unfused).to(dev)
     clf = harness.DGCNNClassifier().to(dev)
     if args.mode == 'train':
         model.train()
@@ -107,6 +108,7 @@ def main() -> None:
                                    f'B={args.batch_per_gpu} per GPU, random-init weights',
                        'global_batch': args.batch_per_gpu * world,
                        'parallelism': f'dp{world}' + (' (DDP all-reduce over RCCL)' if args.mode == 'train' else ' (no collective)')},
+            'edgeconv': 'unfused (reference composition)' if args.unfused else 'fused (no [B,2C,N,k] tensor)',
             'peak_mem_gib': torch.cuda.max_memory_allocated() / 2**30,
         }), flush=True)
     if dist is not None:

@@ -54,6 +54,22 @@ int pcc_graph_max_pool(int b, int c, int n, int k, const float *x, const int64_t
 int pcc_graph_max_pool_bwd(int b, int c, int n, int k, const int64_t *indices, const int32_t *argmax,
                            const float *grad_out, float *grad_x, pcc_stream_t stream);
 
+/* Building blocks of the fused EdgeConv front-end (pointcloudcounterfactual_amd/edgeconv.py): because
+ * the 1x1 convolution is linear, W.[x_j - x_i ; x_i] = Wa.x_j + (Wb - Wa).x_i, so everything the EdgeConv block
+ * (get_graph_features -> conv2d -> BatchNorm2d -> LeakyReLU -> max over k; src/module/encoders.py:50-53,
+ * layers.py:159-203) needs from the [B,2C,N,k] edge tensor can be had from [B,C',N] tensors:
+ *   pcc_neighbour_sum            out[b,c,n] = sum_j y[b,c,indices[b,n,j]]          (BatchNorm statistics)
+ *   pcc_neighbour_sum_bwd        grad_y[b,c,t] = sum_{(n,j): idx=t} grad_out[b,c,n]
+ *   pcc_neighbour_minmax_target  tsel[b,0,c,n] / tsel[b,1,c,n] = the neighbour (point index) with the largest /
+ *                                smallest y among the k neighbours of n (first on ties) -- the edge that survives
+ *                                max-over-k for a positive / negative BatchNorm scale. */
+int pcc_neighbour_sum(int b, int c, int n, int k, const float *y, const int64_t *indices, float *out,
+                      pcc_stream_t stream);
+int pcc_neighbour_sum_bwd(int b, int c, int n, int k, const int64_t *indices, const float *grad_out,
+                          float *grad_y, pcc_stream_t stream);
+int pcc_neighbour_minmax_target(int b, int c, int n, int k, const float *y, const int64_t *indices, int64_t *tsel,
+                                pcc_stream_t stream);
+
 /* Encoder / classifier global pooling (src/module/encoders.py:58,90; classifier.py:63-64):
  * out_max[b,c] = max_n x[b,c,n] with argmax[b,c] (int32, first maximum), out_mean[b,c] = mean_n (either
  * output pointer may be null). */

@@ -15,10 +15,13 @@ namespace {
 //   MODE 0: gather            out[b,c,n,j]  = x[b,c,idx]
 //   MODE 1: graph features    out[b,c,n,j]  = x[b,c,idx] - x[b,c,n] ; out[b,C+c,n,j] = x[b,c,n]
 //   MODE 2: max over k        out[b,c,n]    = max_j x[b,c,idx[n,j]] (+ argmax, first maximum like torch.max)
+//   MODE 3: neighbour sum     out[b,c,n]    = sum_j x[b,c,idx[n,j]]
+//   MODE 4: max AND min over k as TARGET indices: tsel[b,0,c,n] = idx[n, argmax_j], tsel[b,1,c,n] = idx[n, argmin_j]
+//           (what the fused EdgeConv needs: the edge that survives max-over-k for either sign of the BN scale)
 template <int MODE, int CB>
 __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, const float *__restrict__ x,
                                                            const int64_t *__restrict__ indices, float *__restrict__ out,
-                                                           int32_t *__restrict__ argmax) {
+                                                           int32_t *__restrict__ argmax, int64_t *__restrict__ tsel) {
     extern __shared__ __attribute__((aligned(16))) float rows[];  // [CB][n]
     const int smp = blockIdx.y, c0 = blockIdx.x * CB;
     const int tid = threadIdx.x, T = 1024;
@@ -28,7 +31,48 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
     for (int i = tid; i < cb * n; i += T) rows[i] = xb[i];
     __syncthreads();
     const int64_t *ib = indices + (size_t)smp * nk;
-    if (MODE == 2) {
+    if (MODE == 3 || MODE == 4) {
+        for (int i = tid; i < n; i += T) {
+            float acc[CB], lo[CB];
+            int tb[CB], tl[CB];
+#pragma unroll
+            for (int cc = 0; cc < CB; cc++) {
+                acc[cc] = MODE == 3 ? 0.f : -__builtin_inff();
+                lo[cc] = __builtin_inff();
+                tb[cc] = tl[cc] = 0;
+            }
+            for (int j = 0; j < k; j++) {
+                const int t = (int)ib[(size_t)i * k + j];
+#pragma unroll
+                for (int cc = 0; cc < CB; cc++) {
+                    if (cc < cb) {
+                        const float v = rows[cc * n + t];
+                        if (MODE == 3) {
+                            acc[cc] += v;
+                        } else {
+                            const bool gt = (j == 0) || v > acc[cc];
+                            const bool lt = (j == 0) || v < lo[cc];
+                            acc[cc] = gt ? v : acc[cc];
+                            tb[cc] = gt ? t : tb[cc];
+                            lo[cc] = lt ? v : lo[cc];
+                            tl[cc] = lt ? t : tl[cc];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < CB; cc++) {
+                if (cc < cb) {
+                    if (MODE == 3) {
+                        out[((size_t)smp * c + c0 + cc) * n + i] = acc[cc];
+                    } else {
+                        tsel[(((size_t)smp * 2 + 0) * c + c0 + cc) * n + i] = tb[cc];
+                        tsel[(((size_t)smp * 2 + 1) * c + c0 + cc) * n + i] = tl[cc];
+                    }
+                }
+            }
+        }
+    } else if (MODE == 2) {
         for (int i = tid; i < n; i += T) {
             float best[CB];
             int bj[CB];
@@ -89,6 +133,7 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
 // reference's gather backward runs) the float summation order is not fixed.
 //   MODE 0: gather            MODE 1: graph features (adds sum_j g[C+c][i,j] - g[c][i,j] to bin i)
 //   MODE 2: max pool (only the argmax edge of every (c,i) carries gradient)
+//   MODE 3: neighbour sum (every edge (i,j) carries g[b,c,i])
 template <int MODE, int CB>
 __global__ __launch_bounds__(1024) void scatter_lds_kernel(int c, int n, int k, const int64_t *__restrict__ indices,
                                                             const int32_t *__restrict__ argmax,
@@ -121,7 +166,7 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(int c, int n, int k, 
             for (int cc = 0; cc < CB; cc++) {
                 const int ch = c0 + cc;
                 if (ch < c) {
-                    const float v = g[((size_t)smp * gc + ch) * nk + e];
+                    const float v = MODE == 3 ? g[((size_t)smp * c + ch) * n + i] : g[((size_t)smp * gc + ch) * nk + e];
                     atomicAdd(&bins[cc * n + t], v);
                     if (MODE == 1) atomicAdd(&bins[cc * n + i], g[((size_t)smp * gc + c + ch) * nk + e] - v);
                 }
@@ -177,7 +222,7 @@ int check(const char *who, int b, int c, int n, int k) {
 
 template <int MODE>
 int gather_fwd(int b, int c, int n, int k, const float *x, const int64_t *indices, float *out, int32_t *argmax,
-               hipStream_t st, const char *what) {
+               hipStream_t st, const char *what, int64_t *tsel = nullptr) {
     int cb = 8;
     while (cb > 1 && (size_t)cb * n * sizeof(float) > 64 * 1024) cb >>= 1;
     const size_t lds = (size_t)cb * n * sizeof(float);
@@ -189,7 +234,7 @@ int gather_fwd(int b, int c, int n, int k, const float *x, const int64_t *indice
         static bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gather_lds_kernel<MODE, CB>),         \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; \
         (void)attr;                                                                                                 \
-        hipLaunchKernelGGL((gather_lds_kernel<MODE, CB>), grid, dim3(1024), lds, st, c, n, k, x, indices, out, argmax); \
+        hipLaunchKernelGGL((gather_lds_kernel<MODE, CB>), grid, dim3(1024), lds, st, c, n, k, x, indices, out, argmax, tsel); \
     } while (0)
     switch (cb) {
     case 8: PCC_LAUNCH(8); break;
@@ -288,6 +333,35 @@ int pcc_graph_max_pool_bwd(int b, int c, int n, int k, const int64_t *indices, c
     if (!indices || !argmax || !grad_out || !grad_x) return pcc::invalid("graph_max_pool_bwd: null pointer");
     return scatter_bwd<2>(b, c, n, k, indices, argmax, grad_out, grad_x, static_cast<hipStream_t>(stream),
                           "scatter_bwd_kernel<maxpool>");
+}
+
+int pcc_neighbour_sum(int b, int c, int n, int k, const float *x, const int64_t *indices, float *out,
+                      pcc_stream_t stream) {
+    pcc::clear_error();
+    if (int rc = check("neighbour_sum: bad size", b, c, n, k)) return rc;
+    if (b == 0 || n == 0) return PCC_OK;
+    if (!x || !indices || !out) return pcc::invalid("neighbour_sum: null pointer");
+    return gather_fwd<3>(b, c, n, k, x, indices, out, nullptr, static_cast<hipStream_t>(stream), "gather_lds_kernel<nbrsum>");
+}
+
+int pcc_neighbour_sum_bwd(int b, int c, int n, int k, const int64_t *indices, const float *grad_out, float *grad_x,
+                          pcc_stream_t stream) {
+    pcc::clear_error();
+    if (int rc = check("neighbour_sum_bwd: bad size", b, c, n, k)) return rc;
+    if (b == 0 || n == 0) return PCC_OK;
+    if (!indices || !grad_out || !grad_x) return pcc::invalid("neighbour_sum_bwd: null pointer");
+    return scatter_bwd<3>(b, c, n, k, indices, nullptr, grad_out, grad_x, static_cast<hipStream_t>(stream),
+                          "scatter_lds_kernel<nbrsum>");
+}
+
+int pcc_neighbour_minmax_target(int b, int c, int n, int k, const float *x, const int64_t *indices, int64_t *tsel,
+                                pcc_stream_t stream) {
+    pcc::clear_error();
+    if (int rc = check("neighbour_minmax_target: bad size", b, c, n, k)) return rc;
+    if (b == 0 || n == 0) return PCC_OK;
+    if (!x || !indices || !tsel) return pcc::invalid("neighbour_minmax_target: null pointer");
+    return gather_fwd<4>(b, c, n, k, x, indices, nullptr, nullptr, static_cast<hipStream_t>(stream),
+                         "gather_lds_kernel<minmax>", tsel);
 }
 
 int pcc_global_pool(int b, int c, int n, const float *x, float *out_max, int32_t *argmax, float *out_mean,

@@ -27,6 +27,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from pointcloudcounterfactual_amd import neighbour_ops as ops
+from pointcloudcounterfactual_amd.edgeconv import FusedEdgeConv
 from pointcloudcounterfactual_amd.losses import chamfer, match_cost
 
 
@@ -60,12 +61,17 @@ class PointsConv(nn.Module):
 class DGCNNEncoder(nn.Module):
     h_dim = (64, 64, 128, 256)
 
-    def __init__(self, k: int = 25, w_dim: int = 1024) -> None:
+    def __init__(self, k: int = 25, w_dim: int = 1024, fused: bool = True) -> None:
+        """``fused=True`` runs every EdgeConv block through ``FusedEdgeConv`` (same parameters, no [B,2C,N,k] tensor);
+        ``fused=False`` composes it as the reference does (get_graph_features -> conv2d -> BN -> act -> max)."""
         super().__init__()
-        self.k = k
-        layers = [EdgeConv(6, self.h_dim[0], act=False)]
-        for cin, cout in itertools.pairwise(self.h_dim):
-            layers.append(EdgeConv(2 * cin, cout))
+        self.k, self.fused = k, fused
+        if fused:
+            layers: list[nn.Module] = [FusedEdgeConv(3, self.h_dim[0], act=False)]
+            layers += [FusedEdgeConv(cin, cout) for cin, cout in itertools.pairwise(self.h_dim)]
+        else:
+            layers = [EdgeConv(6, self.h_dim[0], act=False)]
+            layers += [EdgeConv(2 * cin, cout) for cin, cout in itertools.pairwise(self.h_dim)]
         self.edge_convolutions = nn.ModuleList(layers)
         self.final_conv = PointsConv(sum(self.h_dim), w_dim, bn=False)
 
@@ -73,8 +79,11 @@ class DGCNNEncoder(nn.Module):
         x = cloud.transpose(2, 1).contiguous()
         xs = []
         for conv in self.edge_convolutions:
-            _idx, feat = ops.get_graph_features(x, torch.empty(0), self.k)  # dynamic graph every layer
-            x = conv(feat).max(dim=3)[0]
+            idx = ops.knn(x, self.k)  # dynamic graph every layer
+            if self.fused:
+                x = conv(x, idx)
+            else:
+                x = conv(ops.get_graph_features(x, idx, self.k)[1]).max(dim=3)[0]
             xs.append(x)
         return self.final_conv(torch.cat(xs, dim=1).contiguous())
 
@@ -88,7 +97,7 @@ class DGCNNClassifier(nn.Module):
     def __init__(self, k: int = 20, n_classes: int = 40) -> None:
         super().__init__()
         self.body = DGCNNEncoder(k=k, w_dim=512)
-        self.body.edge_convolutions[0] = EdgeConv(6, 64)
+        self.body.edge_convolutions[0] = FusedEdgeConv(3, 64)
         self.body.final_conv = PointsConv(512, 512, bn=True)
         self.mlp = nn.Sequential(nn.Linear(1024, 512, bias=False), nn.BatchNorm1d(512), nn.LeakyReLU(0.2), nn.Dropout(0.5),
                                  nn.Linear(512, 256, bias=False), nn.BatchNorm1d(256), nn.LeakyReLU(0.2), nn.Dropout(0.5),
@@ -141,10 +150,11 @@ class PCGenDecoder(nn.Module):
 
 
 class VQAutoencoder(nn.Module):
-    def __init__(self, n_points: int = 2048, k: int = 25, n_codes: int = 256, book_size: int = 16, dim: int = 4) -> None:
+    def __init__(self, n_points: int = 2048, k: int = 25, n_codes: int = 256, book_size: int = 16, dim: int = 4,
+                 fused: bool = True) -> None:
         super().__init__()
         self.n_points, self.n_codes, self.dim = n_points, n_codes, dim
-        self.encoder = DGCNNEncoder(k=k, w_dim=n_codes * dim)
+        self.encoder = DGCNNEncoder(k=k, w_dim=n_codes * dim, fused=fused)
         self.decoder = PCGenDecoder(w_dim=n_codes * dim)
         self.codebook = nn.Parameter(torch.randn(n_codes, book_size, dim))
 

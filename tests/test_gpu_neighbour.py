@@ -133,3 +133,38 @@ def test_global_max_mean_pool(cuda):
     out = ops.global_max_mean_pool(x.to(cuda)).cpu()
     assert torch.equal(out[:, :96], x.max(dim=2)[0])
     torch.testing.assert_close(out[:, 96:], x.mean(dim=2), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('b,c,cout,n,k,act', [(2, 3, 16, 200, 8, False), (2, 16, 32, 257, 20, True), (1, 64, 64, 512, 25, True)])
+def test_fused_edgeconv_matches_unfused_block(cuda, b, c, cout, n, k, act):
+    """FusedEdgeConv == get_graph_features -> Conv2d -> BatchNorm2d(train) -> LeakyReLU -> max over k: outputs, gradients
+    w.r.t. the input and every parameter, and the running statistics."""
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+    from pointcloudcounterfactual_amd.edgeconv import FusedEdgeConv, reference_edgeconv
+
+    torch.manual_seed(c + n)
+    x = _x(n + c, b, c, n).to(cuda)
+    idx = ops.knn(x, k)
+    fused = FusedEdgeConv(c, cout, act=act).to(cuda).train()
+    with torch.no_grad():
+        fused.bn.weight.copy_(torch.randn(cout, device=cuda))             # both signs of the BatchNorm scale
+        fused.bn.bias.copy_(torch.randn(cout, device=cuda))
+    import copy
+    ref = copy.deepcopy(fused)
+    xf = x.clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    of = fused(xf, idx)
+    orf = reference_edgeconv(xr, idx, ref.conv, ref.bn, ref.act)
+    torch.testing.assert_close(of, orf, rtol=2e-4, atol=2e-4)
+    w = torch.randn_like(of)
+    (of * w).sum().backward()
+    (orf * w).sum().backward()
+    torch.testing.assert_close(xf.grad, xr.grad, rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(fused.conv.weight.grad, ref.conv.weight.grad, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(fused.bn.weight.grad, ref.bn.weight.grad, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(fused.bn.bias.grad, ref.bn.bias.grad, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(fused.bn.running_mean, ref.bn.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(fused.bn.running_var, ref.bn.running_var, rtol=1e-4, atol=1e-5)
+    fused.eval(); ref.eval()
+    with torch.no_grad():
+        torch.testing.assert_close(fused(x, idx), reference_edgeconv(x, idx, ref.conv, ref.bn, ref.act), rtol=2e-4, atol=2e-4)
