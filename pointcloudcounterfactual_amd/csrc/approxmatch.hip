@@ -34,6 +34,8 @@ namespace {
 
 using pcc::sq3;
 
+typedef float v4f __attribute__((ext_vector_type(4)));  // for __builtin_nontemporal_load/store
+
 constexpr int kLevels = 9;       // j = 7 .. -1, level = -4^j            (approxmatch.cu:24-25)
 constexpr float kLog2e = 1.44269504088896340736f;
 
@@ -969,7 +971,10 @@ __global__ __launch_bounds__(256) void am_materialise_kernel(int n, int m, const
         float *row = match + ((size_t)smp * m + (l0 + li)) * n;
         if (VEC) {
             if (k0 + 3 < n) {
-                *reinterpret_cast<float4 *>(row + k0) = make_float4(out[0], out[1], out[2], out[3]);
+                // match is written once and read back only after the whole 512 MiB (far beyond the 256 MiB Infinity
+                // Cache): non-temporal stores (A/B on MI355X: materialise 150 -> 127 us)
+                v4f o4 = {out[0], out[1], out[2], out[3]};
+                __builtin_nontemporal_store(o4, reinterpret_cast<v4f *>(row + k0));
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -1059,7 +1064,8 @@ __global__ __launch_bounds__(256) void am_row_kernel(int n, int m, const float *
             for (int k = lane * 4; live && k < cnt; k += 256) {
                 float mv[4];
                 if (VEC && k + 3 < cnt) {
-                    const float4 t = *reinterpret_cast<const float4 *>(mrow + k);
+                    const v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(mrow + k));
+                    const float4 t = make_float4(t4.x, t4.y, t4.z, t4.w);
                     mv[0] = t.x; mv[1] = t.y; mv[2] = t.z; mv[3] = t.w;
                 } else {
 #pragma unroll
@@ -1234,7 +1240,8 @@ __global__ __launch_bounds__(256) void am_grad_fused_kernel(int n, int m, int ro
         if (full) {
 #pragma unroll
             for (int st = 0; st < STEPS; st++) {
-                const float4 t = *reinterpret_cast<const float4 *>(mrow + st * 256 + lane * 4);
+                const v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(mrow + st * 256 + lane * 4));
+                const float4 t = make_float4(t4.x, t4.y, t4.z, t4.w);  // read once: non-temporal (128 -> 119 us)
                 mv[st][0] = t.x; mv[st][1] = t.y; mv[st][2] = t.z; mv[st][3] = t.w;
             }
         } else {
