@@ -112,6 +112,18 @@ int pcc_matchcostgrad(int b, int n, int m, const float *xyz1, const float *xyz2,
 int pcc_matchcostgrad_scaled(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
                              const float *grad_cost, float *grad1, float *grad2, pcc_stream_t stream);
 
+/* ---- match_cost without the match tensor (extension) ---------------------------------------------
+ * The Python-level match_cost (reference structural_losses/match_cost.py:11-50) needs cost[b] in forward and
+ * grad * grad_cost[b] in backward; `match` only travels from ApproxMatch to MatchCost / MatchCostGrad and the
+ * gradient treats it as a constant (approxmatch.cu:229-291).  pcc_match_cost evaluates every match element in
+ * registers (same level order and rounding as pcc_approxmatch) and feeds it straight into the cost and gradient
+ * sums: no 4*b*n*m-byte tensor is written or read.
+ *   cost[b]                     = what pcc_approxmatch + pcc_matchcost return (float summation order differs);
+ *   grad1[b,n,3], grad2[b,m,3]  = what pcc_matchcostgrad_scaled returns; pass both or neither (NULL: cost only);
+ *   grad_cost[b] or NULL (= 1). */
+int pcc_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *grad_cost, float *cost,
+                   float *grad1, float *grad2, pcc_stream_t stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -38,6 +38,7 @@ ABI: dict[str, tuple[object, list[object]]] = {
     'matchcostgrad': (None, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcc_matchcostgrad': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcc_matchcostgrad_scaled': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_match_cost': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     # include/pcc_neighbour.h
     'pcc_knn': (_int, [_int, _int, _int, _int, _vp, _vp, _vp]),
     'pcc_gather_neighbours': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp]),

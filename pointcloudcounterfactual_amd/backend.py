@@ -73,6 +73,30 @@ def ApproxMatchCost(set_d: torch.Tensor, set_q: torch.Tensor) -> list[torch.Tens
     return [match, temp, cost]
 
 
+def MatchCostImplicit(set_d: torch.Tensor, set_q: torch.Tensor, with_grad: bool) -> list[torch.Tensor]:
+    """``match_cost`` without the match tensor (extension, ``pcc_match_cost``): -> [cost[B]] or, ``with_grad``,
+    [cost[B], grad1[B,N,3], grad2[B,M,3]] where the gradients are those of ``MatchCostGrad`` (upstream gradient 1).
+    Every match element is evaluated in registers and consumed on the spot; nothing of size B*M*N touches HBM."""
+    b, n, m = _sizes(set_d, set_q)
+    dev = set_d.device
+    cost = torch.empty((b,), dtype=torch.float32, device=dev)
+    out = [cost]
+    g1 = g2 = None
+    if with_grad:
+        g1 = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+        g2 = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
+        out += [g1, g2]
+    _check_input(set_d, 'set_d')
+    _check_input(set_q, 'set_q')
+    _f32(set_d, 'set_d')
+    _f32(set_q, 'set_q')
+    with torch.cuda.device(dev):
+        _lib.check(_L.pcc_match_cost(b, n, m, set_d.data_ptr(), set_q.data_ptr(), None, cost.data_ptr(),
+                                     g1.data_ptr() if with_grad else None, g2.data_ptr() if with_grad else None,
+                                     _stream(set_d)), 'MatchCostImplicit')
+    return out
+
+
 def MatchCost(set_d: torch.Tensor, set_q: torch.Tensor, match: torch.Tensor) -> torch.Tensor:
     """-> cost[B]   (structural_loss.cpp:40-53)."""
     b, n, m = _sizes(set_d, set_q)

@@ -65,6 +65,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // ---------------------------------------------------------------------------------------------------
 enum Phase { PH_A = 0, PH_B = 1, PH_CA = 2, PH_C = 3 };
 
+constexpr int kDbgInts = 64 + 24 * 19;  // counters + per-phase stamps
 constexpr int kBox = 16;          // points per bounding-box block (sorted order)
 constexpr float kZeroExp = 151.f; // exp2(x) == 0 exactly for x <= -150 (below the smallest f32 subnormal)
 
@@ -91,6 +92,7 @@ struct PhaseArgs {
     float *ratio_out;                  // A: ratioL_0 ; B: ratioR_i ; CA: ratioL_{i+1}
     long long ratio_stride;            // per-sample stride of the level arrays
     int *dbg;                          // optional [2] counters: blocks visited / skipped (debug builds of the host)
+    int *stamp;                        // optional [3][8] s_memrealtime stamps of the first / middle / last workgroup (PCC_AM_DEBUG=2)
 };
 
 // Work-skipping variants of a phase launch.  All of them only drop terms that are EXACTLY zero:
@@ -177,6 +179,7 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
             a.dbg = sc.dbg_counts ? sc.dbg + 4 + 4 * i : nullptr;
         }
     }
+    a.stamp = (sc.dbg && !sc.dbg_counts) ? sc.dbg + 64 + 24 * p : nullptr;
     *mode_out = mode;
     *var_out = var;
     return a;
@@ -256,6 +259,20 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     const float *W0 = W0_CONST ? nullptr : a.w0 + (size_t)smp * a.w0_stride;
     const float *W1 = (NW == 2) ? a.w1 + (size_t)smp * a.w1_stride : nullptr;
 
+    // debug stamps (100 MHz s_memrealtime) of the first, middle and last workgroup of the launch; a.stamp is null in
+    // normal runs (one predicated-off scalar branch per stamp)
+    unsigned long long tst0 = 0;
+    int *stamp = nullptr;
+    if (!PERSIST && a.stamp && threadIdx.x == 0) {
+        const unsigned bx = blockIdx.x, gx = gridDim.x;
+        const int which = bx == 0 ? 0 : bx == gx / 2 ? 1 : bx == gx - 1 ? 2 : -1;
+        if (which >= 0) {
+            stamp = a.stamp + 8 * which;
+            tst0 = __builtin_amdgcn_s_memrealtime();
+            stamp[0] = (int)(tst0 & 0x7fffffff);
+        }
+    }
+#define PCC_ST(k) do { if (stamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[(k)] = (int)(__builtin_amdgcn_s_memrealtime() - tst0); } } while (0)
     // ---- which owners does this workgroup hold? ----
     if (!COWN && tile * TQ >= a.n_own) return;         // (persistent kernel: the two clouds may need different tile counts)
     int n_valid = min(TQ, a.n_own - tile * TQ);  // owners of this tile (sorted positions tile*TQ ...)
@@ -368,6 +385,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         if (MODE != PH_A && !a.first) pre_rem = xld<PERSIST>(&a.remain[(size_t)smp * a.remain_stride + own_e]);
         if (MODE == PH_CA || MODE == PH_C) pre_ratio = xld<PERSIST>(&a.ratio_in[(size_t)smp * a.ratio_stride + own_e]);
     }
+    PCC_ST(1);
     const float4 *X4 = reinterpret_cast<const float4 *>(lds_c);
     const float4 *Y4 = X4 + CH / 4;
     const float4 *Z4 = Y4 + CH / 4;
@@ -399,6 +417,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             }
 #pragma unroll
             for (int j = 0; j < PER; j++) mine += (cv0[j] != 0.f || cv1[j] != 0.f) ? 1 : 0;
+            PCC_ST(2);
             int incl = mine;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -465,6 +484,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             for (int i = tid; i < nblk * 8; i += T) lds_bb[i] = cb[i];
         }
         __syncthreads();
+        PCC_ST(3);
         // blocks are dealt round-robin to the S waves: a contiguous slice of the Hilbert order is one compact
         // region, so contiguous slices would make culling all-or-nothing per wave and leave the workgroup
         // waiting for its nearest slice
@@ -521,12 +541,14 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             }
         }
     }
+    PCC_ST(4);
 #pragma unroll
     for (int r = 0; r < R; r++) {
         red[(0 * S + w) * TQ + r * 64 + lane] = s0[r];
         if (NW == 2) red[(1 * S + w) * TQ + r * 64 + lane] = s1[r];
     }
     __syncthreads();
+    PCC_ST(5);
     if (own_e < 0) return;
     {
         const int e = tid;
@@ -559,6 +581,8 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             if (MODE == PH_CA) xst<PERSIST>(&a.ratio_out[(size_t)smp * a.ratio_stride + o], left / (1e-9f + t1));
         }
     }
+    PCC_ST(6);
+#undef PCC_ST
 }
 
 
@@ -1337,6 +1361,244 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(int rs, size_t per_s
     out[(size_t)smp * per_sample + i] = scale ? s * scale[smp] : s;  // optional upstream gradient (match_cost.py:41-42)
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Implicit match ("pair" kernel): what the Python-level match_cost needs is cost[b] and, when the clouds require
+// gradients, grad1 / grad2 -- never the 512 MiB match tensor itself (reference match_cost.py:25-27,39-42 keeps it on
+// ctx only to feed MatchCostGrad, and the gradient treats match as a constant).  This kernel evaluates every match
+// element in registers exactly as am_materialise_kernel does (same level order, same rounding) and feeds it straight
+// into the cost sum (approxmatch.cu:207-208) and both gradient sums (:239-246, :277-285): no store, no re-read.
+// It runs in the Hilbert-sorted index space of the phase kernels, which buys two exact skips the materialising path
+// cannot have (match is laid out in the caller's order there):
+//   * a level whose exp2(c_i d2) underflows to 0 for every pair (row point, 64Q-column box) is skipped
+//     (wave-uniform; the same test as V_CULL, applied to all levels);
+//   * a row whose live levels are all skipped for this column box contributes exactly 0: no distance, no sqrt.
+// Mapping: workgroup = kPairRT rows (set2 points, sorted) x 64Q columns (set1 points, sorted); a lane owns Q
+// consecutive columns (coordinates, the nine ratioL values and the column sums stay in registers), the 4 waves deal
+// the rows round-robin, row data is broadcast from LDS.  Row sums: per-lane partials are parked in LDS and folded
+// eight rows at a time (48 lanes x 32 sequential adds + one shuffle), so the VALU never runs a 64-lane butterfly per
+// row.  All partials are combined in a fixed order by the second-stage kernels: deterministic.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPairRT = 128;  // rows per workgroup (32 per wave)
+constexpr int kPairRB = 8;    // rows per row-sum fold
+constexpr int kPairPad = 65;  // stash row pitch (floats): lanes of one fold hit distinct banks
+
+struct PairArgs {
+    int n, m, n4, m4;
+    const float *soa1, *soa2;   // [b][3][n4] / [b][3][m4] sorted coordinates
+    const float *lv;            // [b][9][n4 + m4] sorted level rows: ratioL | ratioR
+    LevelConsts lc;
+    float cut2[kLevels];        // a level is exactly 0 beyond this squared distance
+    float *cost_part;           // [b][gridDim.y * gridDim.x]
+    float *part1;               // [b][row_tiles][n4][3]   column sums (grad1, sorted space)
+    float *part2;               // [b][col_blocks][m4][3]  row sums    (grad2, sorted space)
+};
+
+template <int Q, bool GRAD>
+__global__ __launch_bounds__(256) void am_pair_kernel(PairArgs a) {
+    __shared__ float4 lds_l[kPairRT][3];  // (x,y,z,rr0) (rr1..rr4) (rr5..rr8)
+    __shared__ int lds_mask[kPairRT];     // bit i: level i contributes to this row segment
+    __shared__ float stash[GRAD ? 4 * kPairRB * 3 * kPairPad : 4];
+    __shared__ float lds_red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int smp = blockIdx.z;
+    const int l0 = blockIdx.y * kPairRT;
+    const int kb = blockIdx.x * 64 * Q;
+    const int k0 = kb + lane * Q;
+    const size_t nm4 = (size_t)a.n4 + a.m4;
+    const float *lvb = a.lv + (size_t)smp * kLevels * nm4;
+    const float *s1 = a.soa1 + (size_t)smp * 3 * a.n4;
+    const float *s2 = a.soa2 + (size_t)smp * 3 * a.m4;
+    const int lcnt = min(kPairRT, a.m - l0);
+
+    // this thread's row (the first lcnt threads finish one row each once the column box is known)
+    float rowx = 0.f, rowy = 0.f, rowz = 0.f, rowr[kLevels];
+#pragma unroll
+    for (int i = 0; i < kLevels; i++) rowr[i] = 0.f;
+    if (tid < lcnt) {
+        const int l = l0 + tid;
+        rowx = s2[l];
+        rowy = s2[a.m4 + l];
+        rowz = s2[2 * a.m4 + l];
+#pragma unroll
+        for (int i = 0; i < kLevels; i++) rowr[i] = lvb[(size_t)i * nm4 + a.n4 + l];
+    }
+    float x1[Q], y1[Q], z1[Q], rl[kLevels][Q];
+    float blo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
+    float bhi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        const bool real = k0 + q < a.n;
+        const int k = real ? k0 + q : a.n - 1;
+        x1[q] = s1[k];
+        y1[q] = s1[a.n4 + k];
+        z1[q] = s1[2 * a.n4 + k];
+#pragma unroll
+        for (int i = 0; i < kLevels; i++) rl[i][q] = real ? lvb[(size_t)i * nm4 + k] : 0.f;  // a padded column weighs 0
+        blo[0] = fminf(blo[0], x1[q]); bhi[0] = fmaxf(bhi[0], x1[q]);
+        blo[1] = fminf(blo[1], y1[q]); bhi[1] = fmaxf(bhi[1], y1[q]);
+        blo[2] = fminf(blo[2], z1[q]); bhi[2] = fmaxf(bhi[2], z1[q]);
+    }
+    // bounding box of the 64Q columns of this workgroup (every wave holds the same columns)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            blo[c] = fminf(blo[c], __shfl_xor(blo[c], off, 64));
+            bhi[c] = fmaxf(bhi[c], __shfl_xor(bhi[c], off, 64));
+        }
+    }
+    if (tid < lcnt) {
+        // level i adds exactly 0 to the whole row segment if ratioR_i == 0 (exhausted query point,
+        // approxmatch.cu:108-109) or if every exponential underflows: every pair (row, column of the box) has
+        // d2 >= bd2
+        const float bx = fmaxf(fmaxf(blo[0] - rowx, rowx - bhi[0]), 0.f);
+        const float by = fmaxf(fmaxf(blo[1] - rowy, rowy - bhi[1]), 0.f);
+        const float bz = fmaxf(fmaxf(blo[2] - rowz, rowz - bhi[2]), 0.f);
+        const float bd2 = bx * bx + by * by + bz * bz;
+        int mask = 0;
+#pragma unroll
+        for (int i = 0; i < kLevels; i++) mask |= (rowr[i] != 0.f && !(bd2 > a.cut2[i])) ? (1 << i) : 0;
+        lds_l[tid][0] = make_float4(rowx, rowy, rowz, rowr[0]);
+        lds_l[tid][1] = make_float4(rowr[1], rowr[2], rowr[3], rowr[4]);
+        lds_l[tid][2] = make_float4(rowr[5], rowr[6], rowr[7], rowr[8]);
+        lds_mask[tid] = mask;
+    }
+    float g1[Q][3];
+#pragma unroll
+    for (int q = 0; q < Q; q++) g1[q][0] = g1[q][1] = g1[q][2] = 0.f;
+    float csum = 0.f;
+    float *my_stash = stash + (GRAD ? w * kPairRB * 3 * kPairPad : 0);
+    __syncthreads();
+
+    // wave w takes rows w, w+4, ...; kPairRB of them per fold
+    for (int base = 0; base < lcnt; base += 4 * kPairRB) {
+#pragma unroll 1
+        for (int s = 0; s < kPairRB; s++) {
+            const int li = base + 4 * s + w;
+            float rx = 0.f, ry = 0.f, rz = 0.f;
+            const int mask = li < lcnt ? __builtin_amdgcn_readfirstlane(lds_mask[li]) : 0;
+            if (mask) {
+                const float4 A = lds_l[li][0], B = lds_l[li][1], Cc = lds_l[li][2];
+                const float rr[kLevels] = {A.w, B.x, B.y, B.z, B.w, Cc.x, Cc.y, Cc.z, Cc.w};
+                float d[Q], acc[Q];
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    d[q] = sq3(A.x - x1[q], A.y - y1[q], A.z - z1[q]);
+                    acc[q] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < kLevels; i++) {
+                    if (mask & (1 << i)) {
+#pragma unroll
+                        for (int q = 0; q < Q; q++) acc[q] += (fast_exp2(a.lc.c[i] * d[q]) * rl[i][q]) * rr[i];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    if (GRAD) {
+                        // grad1 uses (p1 - p2) (approxmatch.cu:281-284); grad2 the negated vector (:240-246)
+                        const float dx = x1[q] - A.x, dy = y1[q] - A.y, dz = z1[q] - A.z;
+                        // max(d2, 1e-20): d2 is never NaN, so the bare instruction (no canonicalising pre-pass)
+                        float dm;
+                        asm("v_max_f32 %0, %1, %2" : "=v"(dm) : "v"(d[q]), "v"(1e-20f));
+                        const float rs = __builtin_amdgcn_rsqf(dm);
+                        const float f = acc[q] * rs;
+                        // sqrt(d2) = d2 * rsqrt(d2): one transcendental serves both sums (d2 < 1e-20 moves the cost by < 1e-10)
+                        csum = __builtin_fmaf(f, d[q], csum);
+                        const float tx = dx * f, ty = dy * f, tz = dz * f;
+                        g1[q][0] += tx;
+                        g1[q][1] += ty;
+                        g1[q][2] += tz;
+                        rx -= tx;
+                        ry -= ty;
+                        rz -= tz;
+                    } else {
+                        csum = __builtin_fmaf(acc[q], __builtin_amdgcn_sqrtf(d[q]), csum);
+                    }
+                }
+            }
+            if (GRAD) {
+                my_stash[(s * 3 + 0) * kPairPad + lane] = rx;
+                my_stash[(s * 3 + 1) * kPairPad + lane] = ry;
+                my_stash[(s * 3 + 2) * kPairPad + lane] = rz;
+            }
+        }
+        if (GRAD) {
+            // fold the eight rows: lane (v, h) adds half h of vector v = (slot, component) in index order, the two
+            // halves meet through one shuffle.  The stash is private to the wave: no workgroup barrier.
+            const int v = lane % 24, h = lane / 24;
+            float t = 0.f;
+            __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order; keep the compiler to it
+            if (lane < 48) {
+                const float *src = my_stash + v * kPairPad + h * 32;
+#pragma unroll 8
+                for (int i = 0; i < 32; i++) t += src[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float hi = __shfl(t, lane + 24, 64);
+            const int sl = v / 3, c = v - sl * 3;
+            const int li = base + 4 * sl + w;
+            if (lane < 24 && li < lcnt)
+                a.part2[(((size_t)smp * gridDim.x + blockIdx.x) * a.m4 + (l0 + li)) * 3 + c] = t + hi;
+        }
+    }
+    // cost partial of this workgroup
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) csum += __shfl_down(csum, off, 64);
+    if (lane == 0) lds_red[w] = csum;
+    __syncthreads();
+    if (tid == 0)
+        a.cost_part[(size_t)smp * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x] =
+            ((lds_red[0] + lds_red[1]) + lds_red[2]) + lds_red[3];
+    if (GRAD) {
+        // column sums: waves 1..3 hand theirs to wave 0 one after the other (fixed order); the stash is free now
+        static_assert(Q * 3 * 64 <= 4 * kPairRB * 3 * kPairPad, "column merge reuses the stash");
+        for (int src = 1; src < 4; src++) {
+            __syncthreads();
+            if (w == src) {
+#pragma unroll
+                for (int q = 0; q < Q; q++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) stash[(q * 3 + c) * 64 + lane] = g1[q][c];
+            }
+            __syncthreads();
+            if (w == 0) {
+#pragma unroll
+                for (int q = 0; q < Q; q++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) g1[q][c] += stash[(q * 3 + c) * 64 + lane];
+            }
+        }
+        if (w == 0) {
+            float *dst = a.part1 + (((size_t)smp * gridDim.y + blockIdx.y) * a.n4) * 3;
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                if (k0 + q < a.n) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) dst[(size_t)(k0 + q) * 3 + c] = g1[q][c];
+                }
+            }
+        }
+    }
+}
+
+// out[b][i][:] = scale[b] * sum_t part[b][t][rank[b][i]][:] -- second stage of the implicit-match gradients: adds the
+// partials in index order and carries the result from the sorted index space back to the caller's point order.
+__global__ __launch_bounds__(256) void reduce_unsort_kernel(int parts, int npts, int pitch, const float *__restrict__ part,
+                                                             const int *__restrict__ rank, const float *__restrict__ scale,
+                                                             float *__restrict__ out) {
+    const int smp = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= npts * 3) return;
+    const int pt = i / 3, c = i - pt * 3;
+    const int s = rank[(size_t)smp * npts + pt];
+    const float *p = part + ((size_t)smp * parts * pitch + s) * 3 + c;
+    float acc = p[0];
+    for (int t = 1; t < parts; t++) acc += p[(size_t)t * pitch * 3];
+    out[(size_t)smp * npts * 3 + i] = scale ? acc * scale[smp] : acc;
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 constexpr int kPhCH = 2048;
 
@@ -1519,20 +1781,16 @@ int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const
     return pcc::check_launch("approxmatch(sort)");
 }
 
-int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
-                     void *workspace, size_t workspace_bytes, float *cost_out, hipStream_t st) {
-    const WsLayout L(b, n, m);
-    if (workspace_bytes < L.total) return pcc::invalid("approxmatch: workspace too small");
-    if (!aligned16(workspace)) return pcc::invalid("approxmatch: workspace must be 16-byte aligned");
-    char *base = static_cast<char *>(workspace);
+// Sort + the 19 passes: leaves the nine (ratioL | ratioR) level rows and remainL | remainR in the workspace, in the
+// Hilbert-sorted index space.
+int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const WsLayout &L, char *base, hipStream_t st,
+               bool *persist_out) {
     float *soa1 = reinterpret_cast<float *>(base + L.soa1), *soa2 = reinterpret_cast<float *>(base + L.soa2);
     int *rank1 = reinterpret_cast<int *>(base + L.rank1), *rank2 = reinterpret_cast<int *>(base + L.rank2);
     float *box1 = reinterpret_cast<float *>(base + L.box1), *box2 = reinterpret_cast<float *>(base + L.box2);
     float *box64_1 = reinterpret_cast<float *>(base + L.box64_1), *box64_2 = reinterpret_cast<float *>(base + L.box64_2);
     float *rem = reinterpret_cast<float *>(base + L.rem);
     float *lv = reinterpret_cast<float *>(base + L.lv);
-    float *lv_orig = reinterpret_cast<float *>(base + L.lv_orig);
-    float *cpart = reinterpret_cast<float *>(base + L.cpart);
     const LevelConsts lc = make_levels();
     float multiL, multiR;  // approxmatch.cu:6-12 (integer division)
     if (n >= m) { multiL = 1; multiR = (float)(n / m); }
@@ -1560,8 +1818,8 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
     static int *dbg_counters = [] {
         int *p = nullptr;
         const char *e = std::getenv("PCC_AM_DEBUG");
-        if (e && (e[0] == '1' || e[0] == '2') && hipMalloc(reinterpret_cast<void **>(&p), 64 * sizeof(int)) == hipSuccess)
-            (void)hipMemset(p, 0, 64 * sizeof(int));
+        if (e && (e[0] == '1' || e[0] == '2') && hipMalloc(reinterpret_cast<void **>(&p), kDbgInts * sizeof(int)) == hipSuccess)
+            (void)hipMemset(p, 0, kDbgInts * sizeof(int));
         return p;
     }();
     static const int dbg_counts = [] {
@@ -1632,16 +1890,46 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         }
     }
     if (dbg_counters) {
-        int h[64];
+        static int h[kDbgInts];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, dbg_counters, sizeof h, hipMemcpyDeviceToHost);
         std::fprintf(stderr, "[pcc dbg] A: %d/%d skipped;", h[1], h[0]);
         for (int i = 0; i < kLevels; i++) std::fprintf(stderr, " B%d %d/%d CA%d %d/%d;", i, h[3 + 4 * i], h[2 + 4 * i], i, h[5 + 4 * i], h[4 + 4 * i]);
+        if (!dbg_counts) {
+            std::fprintf(stderr, "\n[pcc dbg] phase stamps x10ns (first | middle | last workgroup): start-after-first [prologue loads staged loop reduced end]");
+            for (int q = 0; q < sched_phases(); q++) {
+                const int *s = h + 64 + 24 * q;
+                std::fprintf(stderr, "\n[pcc dbg]  p%02d", q);
+                for (int k = 0; k < 3; k++) {
+                    const int *t = s + 8 * k;
+                    std::fprintf(stderr, " | +%d [%d %d %d %d %d %d]", (t[0] - s[0]) & 0x7fffffff, t[1], t[2], t[3], t[4], t[5], t[6]);
+                }
+            }
+        }
         std::fprintf(stderr, "\n[pcc dbg] persistent block 0, per pass body/barrier x10ns:");
         for (int q = 0; q < sched_phases(); q++) std::fprintf(stderr, " %d/%d", (unsigned)h[40 + q] >> 16, h[40 + q] & 0xffff);
         std::fprintf(stderr, "\n");
         (void)hipMemset(dbg_counters, 0, sizeof h);
     }
+    *persist_out = use_persist;
+    return PCC_OK;
+}
+
+int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                     void *workspace, size_t workspace_bytes, float *cost_out, hipStream_t st) {
+    const WsLayout L(b, n, m);
+    if (workspace_bytes < L.total) return pcc::invalid("approxmatch: workspace too small");
+    if (!aligned16(workspace)) return pcc::invalid("approxmatch: workspace must be 16-byte aligned");
+    char *base = static_cast<char *>(workspace);
+    bool use_persist = false;
+    int rc = run_levels(b, n, m, xyz1, xyz2, L, base, st, &use_persist);
+    if (rc) return rc;
+    int *rank1 = reinterpret_cast<int *>(base + L.rank1), *rank2 = reinterpret_cast<int *>(base + L.rank2);
+    float *rem = reinterpret_cast<float *>(base + L.rem);
+    float *lv = reinterpret_cast<float *>(base + L.lv);
+    float *lv_orig = reinterpret_cast<float *>(base + L.lv_orig);
+    float *cpart = reinterpret_cast<float *>(base + L.cpart);
+    const LevelConsts lc = make_levels();
     hipLaunchKernelGGL(am_unpermute_kernel, dim3(pcc::ceil_div(n + m, 256), b), dim3(256), 0, st, n, m, L.n4, L.m4, lv, rem,
                        rank1, rank2, use_persist ? reinterpret_cast<const unsigned *>(base + L.sync) + b : nullptr, lv_orig, temp);
     rc = pcc::check_launch("approxmatch(unpermute)");
@@ -1665,6 +1953,60 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
         else hipLaunchKernelGGL((am_materialise_kernel<false, false>), grid, dim3(256), 0, st, n, m, xyz1, xyz2, lv_orig, lc, match, nullptr);
     }
     return pcc::check_launch("approxmatch(materialise)");
+}
+
+// cost[b] (and grad1 / grad2 when both are non-null) of the Python-level match_cost without materialising match.
+template <int Q>
+int launch_pair(const PairArgs &pa, dim3 grid, bool grad, hipStream_t st) {
+    pcc::ProfScope prof(grad ? "am_pair_kernel<grad>" : "am_pair_kernel<cost>", st);
+    if (grad) hipLaunchKernelGGL((am_pair_kernel<Q, true>), grid, dim3(256), 0, st, pa);
+    else hipLaunchKernelGGL((am_pair_kernel<Q, false>), grid, dim3(256), 0, st, pa);
+    return pcc::check_launch("match_cost(pair)");
+}
+
+int match_cost_implicit_impl(int b, int n, int m, const float *xyz1, const float *xyz2, const float *grad_cost,
+                             float *cost, float *grad1, float *grad2, hipStream_t st) {
+    const WsLayout L(b, n, m);
+    static const int q_cols = [] {  // columns per lane (A/B measurements: PCC_AM_PAIRQ=2|4)
+        const char *e = std::getenv("PCC_AM_PAIRQ");
+        const int v = e ? std::atoi(e) : 4;
+        return v == 2 ? 2 : 4;
+    }();
+    const bool grad = grad1 && grad2;
+    const int col_blocks = pcc::ceil_div(n, 64 * q_cols), row_tiles = pcc::ceil_div(m, kPairRT);
+    auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t cpart_off = up(L.total);
+    const size_t part1_off = up(cpart_off + (size_t)b * col_blocks * row_tiles * 4);
+    const size_t part2_off = up(part1_off + (grad ? (size_t)b * row_tiles * L.n4 * 3 * 4 : 0));
+    const size_t total = up(part2_off + (grad ? (size_t)b * col_blocks * L.m4 * 3 * 4 : 0));
+    StreamBuf ws(st);
+    if (int rc = ws.alloc(total)) return rc;
+    char *base = static_cast<char *>(ws.p);
+    bool use_persist = false;
+    int rc = run_levels(b, n, m, xyz1, xyz2, L, base, st, &use_persist);
+    if (rc) return rc;
+    PairArgs pa{};
+    pa.n = n; pa.m = m; pa.n4 = L.n4; pa.m4 = L.m4;
+    pa.soa1 = reinterpret_cast<const float *>(base + L.soa1);
+    pa.soa2 = reinterpret_cast<const float *>(base + L.soa2);
+    pa.lv = reinterpret_cast<const float *>(base + L.lv);
+    pa.lc = make_levels();
+    for (int i = 0; i < kLevels; i++) pa.cut2[i] = kZeroExp / -pa.lc.c[i];
+    pa.cost_part = reinterpret_cast<float *>(base + cpart_off);
+    pa.part1 = grad ? reinterpret_cast<float *>(base + part1_off) : nullptr;
+    pa.part2 = grad ? reinterpret_cast<float *>(base + part2_off) : nullptr;
+    const dim3 grid(col_blocks, row_tiles, b);
+    rc = q_cols == 2 ? launch_pair<2>(pa, grid, grad, st) : launch_pair<4>(pa, grid, grad, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(b), dim3(256), 0, st, col_blocks * row_tiles, pa.cost_part, cost);
+    if (grad) {
+        const int *rank1 = reinterpret_cast<const int *>(base + L.rank1), *rank2 = reinterpret_cast<const int *>(base + L.rank2);
+        hipLaunchKernelGGL(reduce_unsort_kernel, dim3(pcc::ceil_div(n * 3, 256), b), dim3(256), 0, st, row_tiles, n, L.n4,
+                           pa.part1, rank1, grad_cost, grad1);
+        hipLaunchKernelGGL(reduce_unsort_kernel, dim3(pcc::ceil_div(m * 3, 256), b), dim3(256), 0, st, col_blocks, m, L.m4,
+                           pa.part2, rank2, grad_cost, grad2);
+    }
+    return pcc::check_launch("match_cost(reduce)");
 }
 
 int check_sizes(const char *who, int b, int n, int m) {
@@ -1721,6 +2063,24 @@ int pcc_approxmatch_cost(int b, int n, int m, const float *xyz1, const float *xy
     const size_t bytes = pcc_approxmatch_workspace_bytes(b, n, m);
     if (int rc = ws.alloc(bytes)) return rc;
     return approxmatch_impl(b, n, m, xyz1, xyz2, match, temp, ws.p, bytes, cost, st);
+}
+
+int pcc_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *grad_cost, float *cost,
+                   float *grad1, float *grad2, pcc_stream_t stream) {
+    pcc::clear_error();
+    if (int rc = check_sizes("match_cost: bad size", b, n, m)) return rc;
+    if (b == 0) return PCC_OK;
+    if (!cost) return pcc::invalid("match_cost: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n == 0 || m == 0) {  // empty sums
+        hipError_t e = hipMemsetAsync(cost, 0, (size_t)b * sizeof(float), st);
+        if (n && grad1 && e == hipSuccess) e = hipMemsetAsync(grad1, 0, (size_t)b * n * 3 * sizeof(float), st);
+        if (m && grad2 && e == hipSuccess) e = hipMemsetAsync(grad2, 0, (size_t)b * m * 3 * sizeof(float), st);
+        return e == hipSuccess ? PCC_OK : (pcc::set_error((int)e, "match_cost: memset failed"), (int)e);
+    }
+    if (!xyz1 || !xyz2) return pcc::invalid("match_cost: null pointer");
+    if ((grad1 == nullptr) != (grad2 == nullptr)) return pcc::invalid("match_cost: grad1 and grad2 go together");
+    return match_cost_implicit_impl(b, n, m, xyz1, xyz2, grad_cost, cost, grad1, grad2, st);
 }
 
 void approxmatch(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,

@@ -39,29 +39,52 @@ class NNDistanceFunction(Function):
 
 
 class MatchCostFunction(Function):
-    """``(set1[B,N,3], set2[B,M,3]) -> cost[B]`` approximate earth mover's distance."""
+    """``(set1[B,N,3], set2[B,M,3]) -> cost[B]`` approximate earth mover's distance.
 
-    # One pass materialises ``match`` and accumulates the cost (pcc_approxmatch_cost); set to False to
-    # run the reference's two backend calls ApproxMatch -> MatchCost (match_cost.py:25-27) instead.
-    fused_forward = True
+    ``mode`` selects how the reference's ApproxMatch -> MatchCost / MatchCostGrad sequence (match_cost.py:25-27,
+    39-42) is carried out; the three give the same cost and gradients up to float summation order:
+
+    * ``'implicit'`` (default): ``match`` never exists.  One pass evaluates every match element in registers and
+      accumulates the cost and -- when an input requires grad -- both gradients (they depend on the inputs only:
+      the reference treats ``match`` as a constant); backward multiplies by ``grad_output``.  Saves the 4*B*M*N-byte
+      tensor the reference keeps alive on ``ctx`` (512 MiB at B=32, N=2048) and two full passes over it.
+    * ``'fused'``: ``match`` is materialised once (cost accumulated by the same pass) and read once in backward.
+    * ``'reference'``: the reference's three backend calls, one after the other.
+    """
+
+    mode = 'implicit'
 
     @staticmethod
     def forward(ctx: Any, *args: torch.Tensor, **kwargs: Any) -> torch.Tensor:
         set1, set2, *_ = args
+        mode = MatchCostFunction.mode
+        ctx.mode = mode
+        if mode == 'implicit':
+            with_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+            out = backend.MatchCostImplicit(set1, set2, with_grad)
+            if with_grad:
+                ctx.save_for_backward(out[1], out[2])
+            return out[0]
         ctx.save_for_backward(set1, set2)
-        if MatchCostFunction.fused_forward:
+        if mode == 'fused':
             match, _temp, cost = backend.ApproxMatchCost(set1, set2)
-        else:
+        elif mode == 'reference':
             match, _temp = backend.ApproxMatch(set1, set2)
             cost = backend.MatchCost(set1, set2, match)
+        else:
+            raise ValueError(f'unknown MatchCostFunction.mode {mode!r}')
         ctx.match = match  # kept alive until backward, as the reference does (match_cost.py:26)
         return cost
 
     @staticmethod
     def backward(ctx: Any, *grad_outputs: Any) -> tuple[torch.Tensor, torch.Tensor]:
         grad_output = grad_outputs[0]
+        if ctx.mode == 'implicit':
+            grad1, grad2 = ctx.saved_tensors
+            scale = grad_output.unsqueeze(1).unsqueeze(2)
+            return grad1 * scale, grad2 * scale
         set1, set2 = ctx.saved_tensors
-        if MatchCostFunction.fused_forward:  # upstream gradient folded into the reduction of the gradient kernel
+        if ctx.mode == 'fused':  # upstream gradient folded into the reduction of the gradient kernel
             grad1, grad2 = backend.MatchCostGradScaled(set1, set2, ctx.match, grad_output.contiguous().float())
             return grad1, grad2
         grad1, grad2 = backend.MatchCostGrad(set1, set2, ctx.match)

@@ -292,24 +292,111 @@ def test_bit_reproducible_run_to_run(cuda):
         assert all(torch.equal(x, y) for x, y in zip(g1, g2))
 
 
-def test_match_cost_autograd_fused_vs_reference_sequence(cuda):
-    """match_cost through the fused entry points (pcc_approxmatch_cost, pcc_matchcostgrad_scaled) == the reference's
-    call sequence ApproxMatch -> MatchCost -> MatchCostGrad -> grad * grad_output (match_cost.py:25-42)."""
+def test_match_cost_autograd_modes_agree(cuda):
+    """match_cost in its three modes -- 'implicit' (pcc_match_cost: no match tensor), 'fused' (pcc_approxmatch_cost,
+    pcc_matchcostgrad_scaled) and 'reference' (the reference's call sequence ApproxMatch -> MatchCost ->
+    MatchCostGrad -> grad * grad_output, match_cost.py:25-42) -- gives the same cost and gradients."""
     from pointcloudcounterfactual_amd.losses import MatchCostFunction, match_cost
 
     a, c = pair(23, 3, 700, 512)
     w = torch.tensor([0.5, -2.0, 3.0], device=cuda)
-    res = []
+    res = {}
     try:
-        for fused in (True, False):
-            MatchCostFunction.fused_forward = fused
+        for mode in ('reference', 'fused', 'implicit'):
+            MatchCostFunction.mode = mode
             t1 = _dev(a, cuda).requires_grad_(True)
             t2 = _dev(c, cuda).requires_grad_(True)
             cost = match_cost(t1, t2)
             (cost * w).sum().backward()
-            res.append((cost.detach(), t1.grad, t2.grad))
+            res[mode] = (cost.detach().cpu().numpy(), t1.grad.cpu().numpy(), t2.grad.cpu().numpy())
     finally:
-        MatchCostFunction.fused_forward = True
-    np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), rtol=1e-5)
+        MatchCostFunction.mode = 'implicit'
+    ref = res['reference']
+    np.testing.assert_allclose(res['fused'][0], ref[0], rtol=1e-5)
+    np.testing.assert_allclose(res['implicit'][0], ref[0], rtol=1e-5)
+    scale = max(np.abs(ref[1]).max(), np.abs(ref[2]).max())
     for k in (1, 2):
-        np.testing.assert_allclose(res[0][k].cpu().numpy(), res[1][k].cpu().numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(res['fused'][k], ref[k], rtol=1e-6, atol=1e-7)
+        # same match elements bit for bit; only the order of the row / column sums differs
+        np.testing.assert_allclose(res['implicit'][k], ref[k], rtol=1e-5, atol=1e-5 * scale)
+
+
+IM_SHAPES = [(1, 1, 1), (2, 3, 5), (2, 64, 64), (2, 257, 130), (2, 128, 256), (1, 513, 512), (2, 1024, 1024),
+             (1, 2100, 2300), (1, 4099, 100), (2, 70, 2050), (4, 2048, 2048)]
+
+
+@pytest.mark.parametrize('b,n,m', IM_SHAPES)
+@pytest.mark.parametrize('kind', ['recon', 'uniform'])
+def test_implicit_match_cost_equals_materialised(cuda, b, n, m, kind):
+    """pcc_match_cost (match never stored; sorted index space, exact-zero levels skipped per column box) against the
+    materialised path of the same library: the match elements are the same bits, so cost and gradients agree to the
+    rounding of the differently ordered sums (1e-5 of the largest gradient component)."""
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(900 + n + m, b, n, m, kind)
+    t1, t2 = _dev(a, cuda), _dev(c, cuda)
+    match, _temp, cost = backend.ApproxMatchCost(t1, t2)
+    g1, g2 = backend.MatchCostGrad(t1, t2, match)
+    only_cost, = backend.MatchCostImplicit(t1, t2, False)
+    cost_i, h1, h2 = backend.MatchCostImplicit(t1, t2, True)
+    # the gradient variant takes sqrt(d2) as d2 * rsqrt(max(d2, 1e-20)) (one transcendental for cost and gradient)
+    np.testing.assert_allclose(only_cost.cpu().numpy(), cost_i.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(cost_i.cpu().numpy(), cost.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    scale = max(float(g1.abs().max()), float(g2.abs().max()), 1e-30)
+    np.testing.assert_allclose(h1.cpu().numpy(), g1.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(h2.cpu().numpy(), g2.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize('b,n,m', [(2, 3, 5), (2, 257, 130), (2, 1024, 1024)])
+def test_implicit_match_cost_vs_oracle(cuda, oracle_mod, b, n, m):
+    """pcc_match_cost against the float64 recurrence of the oracle: cost to 1e-5 (north_star), gradients within the
+    oracle's own f32-vs-f64 spread (the match elements are ill-conditioned, see test_approxmatch_vs_oracle)."""
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(300 + n + m, b, n, m)
+    cost, g1, g2 = backend.MatchCostImplicit(_dev(a, cuda), _dev(c, cuda), True)
+    om, _ = oracle_mod.approxmatch(a, c)
+    om64, _ = oracle_mod.approxmatch_f64(a, c)
+    oc64 = oracle_mod.matchcost_f64(a, c, om64)
+    oc32 = oracle_mod.matchcost(a, c, om)
+    tol = max(1e-5, 4 * np.abs(oc32 - oc64).max() / max(np.abs(oc64).max(), 1e-30))
+    np.testing.assert_allclose(cost.cpu().numpy(), oc64, rtol=tol, atol=1e-7)
+    h1, h2 = oracle_mod.matchcostgrad_f64(a, c, om64)
+    f1, f2 = oracle_mod.matchcostgrad(a, c, om)
+    scale = max(np.abs(h1).max(), np.abs(h2).max())
+    spread = max(np.abs(f1 - h1).max(), np.abs(f2 - h2).max())
+    assert np.abs(g1.cpu().numpy() - h1).max() <= max(10 * spread, 1e-5 * scale)
+    assert np.abs(g2.cpu().numpy() - h2).max() <= max(10 * spread, 1e-5 * scale)
+
+
+def test_implicit_match_cost_edge_cases(cuda):
+    from pointcloudcounterfactual_amd import backend
+
+    # far clouds: every exponential underflows -> no mass, cost 0, zero gradients (SURVEY 8(c) quirk)
+    a, c = pair(5, 2, 300, 300)
+    t1, t2 = _dev(a, cuda), _dev(c + 40.0, cuda)
+    cost, g1, g2 = backend.MatchCostImplicit(t1, t2, True)
+    assert float(cost.abs().max()) == 0.0 and float(g1.abs().max()) == 0.0 and float(g2.abs().max()) == 0.0
+    # identical clouds: all mass on the diagonal, d = 0 -> cost ~ 0 and finite gradients (rsqrt(max(d2, 1e-20)))
+    t = _dev(a, cuda)
+    cost, g1, g2 = backend.MatchCostImplicit(t, t, True)
+    assert torch.isfinite(g1).all() and torch.isfinite(g2).all()
+    ref_cost = backend.ApproxMatchCost(t, t)[2]
+    np.testing.assert_allclose(cost.cpu().numpy(), ref_cost.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # empty batch / empty clouds
+    e = torch.empty(0, 5, 3, device=cuda)
+    assert backend.MatchCostImplicit(e, e, True)[0].shape == (0,)
+    z1, z2 = torch.zeros(2, 0, 3, device=cuda), torch.zeros(2, 4, 3, device=cuda)
+    cost, g1, g2 = backend.MatchCostImplicit(z1, z2, True)
+    assert float(cost.abs().sum()) == 0.0 and g1.shape == (2, 0, 3) and float(g2.abs().sum()) == 0.0
+
+
+def test_implicit_match_cost_bit_reproducible(cuda):
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(32, 8, 2048, 2048)
+    t1, t2 = _dev(a, cuda), _dev(c, cuda)
+    r1 = backend.MatchCostImplicit(t1, t2, True)
+    for _ in range(3):
+        r2 = backend.MatchCostImplicit(t1, t2, True)
+        assert all(torch.equal(x, y) for x, y in zip(r1, r2))

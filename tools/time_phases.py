@@ -20,3 +20,19 @@ for name in names:
     L.pcc_profile_read(name, ctypes.byref(us), ctypes.byref(n))
     print(name.decode(), f'{us.value:.1f} us x{n.value}')
 print('cost check', float(match.sum()))
+import time
+cost = torch.empty(B, device=dev); g1 = torch.empty(B, N, 3, device=dev); g2 = torch.empty(B, N, 3, device=dev)
+for grad in (False, True):
+    L.pcc_profile_enable(0)
+    args = (B, N, N, t1.data_ptr(), t2.data_ptr(), None, cost.data_ptr(), g1.data_ptr() if grad else None, g2.data_ptr() if grad else None, st)
+    for _ in range(3): L.pcc_match_cost(*args)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): L.pcc_match_cost(*args)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+    L.pcc_profile_enable(1)
+    for _ in range(5): L.pcc_match_cost(*args)
+    torch.cuda.synchronize()
+    us = ctypes.c_double(); n = ctypes.c_int()
+    L.pcc_profile_read(b'am_pair_kernel', ctypes.byref(us), ctypes.byref(n))
+    print(f'pcc_match_cost grad={grad}: {dt*1e6:.1f} us per call; am_pair_kernel {us.value:.1f} us x{n.value}; cost sum {float(cost.sum()):.6f}')
+
