@@ -48,6 +48,9 @@ def parse() -> argparse.Namespace:
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-clouds', type=int, default=0, help='clouds in the CPU-baseline sample (0 = auto)')
+    ap.add_argument('--emd-mode', choices=['implicit', 'fused', 'reference'], default='implicit',
+                    help="how match_cost carries out ApproxMatch -> MatchCost / MatchCostGrad (losses.MatchCostFunction.mode): "
+                         "'implicit' never stores match; 'fused' / 'reference' materialise the [B,M,N] tensor")
     return ap.parse_args()
 
 
@@ -99,9 +102,12 @@ def kernel_breakdown(recon_t, ref_t, steps: int) -> dict[str, float]:
         kt.time('nndistance', lambda: out.__setitem__('nn', backend.NNDistance(recon_t, ref_t)))
         d1, i1, d2, i2 = out['nn']
         kt.time('nndistancegrad', lambda: backend.NNDistanceGrad(recon_t, ref_t, i1, i2, g, g))
+        kt.time('match_cost_implicit_fwd_bwd', lambda: backend.MatchCostImplicit(recon_t, ref_t, True))
+        kt.time('match_cost_implicit_fwd_only', lambda: backend.MatchCostImplicit(recon_t, ref_t, False))
         kt.time('approxmatch_cost', lambda: out.__setitem__('am', backend.ApproxMatchCost(recon_t, ref_t)))
         match = out['am'][0]
         kt.time('matchcostgrad', lambda: backend.MatchCostGrad(recon_t, ref_t, match))
+        out['am'] = match = None
     torch.cuda.synchronize()
     return {k: kt.avg_us(k) for k in kt.records}
 
@@ -118,7 +124,7 @@ def phase_kernel_time_us(recon_t, ref_t, steps: int) -> tuple[float, int]:
         return float('nan'), 0
     L.pcc_profile_enable(1)
     for _ in range(steps):
-        backend.ApproxMatchCost(recon_t, ref_t)
+        backend.MatchCostImplicit(recon_t, ref_t, True)
     torch.cuda.synchronize()
     import ctypes
 
@@ -138,7 +144,7 @@ def cpu_baseline(recon: np.ndarray, ref: np.ndarray, clouds: int) -> dict:
     oracle.set_threads(threads)
     a, c = recon[:clouds], ref[:clouds]
     n = a.shape[1]
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()  # the oracle follows the reference's data flow: match is materialised and re-read
     d1, i1, d2, i2 = oracle.nndistance(a, c)
     g = np.full_like(d1, 1.0 / n)
     oracle.nndistancegrad(a, c, i1, i2, g, g)
@@ -178,6 +184,9 @@ def main() -> None:
 
     import pointcloudcounterfactual_amd  # noqa: F401  (raises if the HIP library is missing)
 
+    from pointcloudcounterfactual_amd.losses import MatchCostFunction
+
+    MatchCostFunction.mode = args.emd_mode
     recon, ref, recon_t, ref_t = make_inputs(rank, dev)
     recon_t.requires_grad_(True)
 
@@ -217,6 +226,7 @@ def main() -> None:
         'config': {
             'workload': 'BASELINE configs[1]+[2]: N=2048 B=32 per GPU, nn_distance (Chamfer, mean) fwd+bwd + '
                         'match_cost (approxmatch+matchcost) fwd+bwd through the autograd surface',
+            'emd_mode': args.emd_mode,
             'batch_per_gpu': B_PER_GPU,
             'n_points': N_POINTS,
             'global_batch': B_PER_GPU * world,
@@ -225,6 +235,22 @@ def main() -> None:
     }
 
     if rank == 0:
+        if args.emd_mode == 'implicit':
+            # the same step with match materialised (reference data flow: 4*B*M*N bytes written once, read once)
+            MatchCostFunction.mode = 'fused'
+            k2 = max(3, min(args.steps, 20))
+            for _ in range(2):
+                step(recon_t, ref_t)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                step(recon_t, ref_t)
+            torch.cuda.synchronize()
+            result['materialised_match_path'] = {
+                'clouds_per_s_this_rank': B_PER_GPU * k2 / (time.perf_counter() - t1), 'steps': k2,
+                'note': "match_cost mode 'fused': match[B,M,N] written by am_materialise_kernel and read back by "
+                        "am_grad_fused_kernel; same cost and gradients (tests/test_gpu_structural.py)"}
+            MatchCostFunction.mode = args.emd_mode
         with torch.no_grad():
             br = kernel_breakdown(recon_t.detach(), ref_t, max(3, min(args.steps, 20)))
             phase_us, phase_cnt = phase_kernel_time_us(recon_t.detach(), ref_t, max(3, min(args.steps, 20)))
@@ -265,7 +291,8 @@ def main() -> None:
             'clouds_per_s': B_PER_GPU / (ch_us * 1e-6),
         }
         result['breakdown_us'] = br
-        result['emd_clouds_per_s'] = B_PER_GPU / ((br['approxmatch_cost'] + br['matchcostgrad']) * 1e-6)
+        result['emd_clouds_per_s'] = B_PER_GPU / (br['match_cost_implicit_fwd_bwd'] * 1e-6)
+        result['emd_clouds_per_s_materialised'] = B_PER_GPU / ((br['approxmatch_cost'] + br['matchcostgrad']) * 1e-6)
         if world == 1 and not args.no_cpu_baseline:
             ncl = args.cpu_clouds or min(B_PER_GPU, max(2, os.cpu_count() or 2))
             result['cpu_baseline'] = cpu_baseline(recon, ref, ncl)
