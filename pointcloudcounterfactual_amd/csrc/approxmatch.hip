@@ -91,6 +91,9 @@ struct PhaseArgs {
     const float *ratio_in;             // CA/C: ratioL_i
     float *ratio_out;                  // A: ratioL_0 ; B: ratioR_i ; CA: ratioL_{i+1}
     long long ratio_stride;            // per-sample stride of the level arrays
+    float *clist;                      // dense candidate list [b][5][cl_n4]: x | y | z | ratioR | remainR (V_COWN writes, V_CLIST reads)
+    int *clist_cnt;                    // [b] entries in the list
+    int cl_n4;
     int *dbg;                          // optional [2] counters: blocks visited / skipped (debug builds of the host)
     int *stamp;                        // optional [3][8] s_memrealtime stamps of the first / middle / last workgroup (PCC_AM_DEBUG=2)
 };
@@ -104,7 +107,11 @@ struct PhaseArgs {
 //   V_COWN  (pass B from level 3 on): the same exhausted points as OWNERS: their outputs are ratioR = 0,
 //           remainR = 0 whatever the sum is, so only the live owners are gathered into tiles (the level arrays
 //           are zero-filled beforehand) and workgroups beyond the live count exit.
-enum Var { V_PLAIN = 0, V_CULL = 1, V_CCAND = 2, V_COWN = 3 };
+//   V_CLIST (pass C/A from level 3 on): the same candidates as V_CCAND, but the compaction is already done: the live
+//           owners of the preceding V_COWN pass B ARE the candidates with a non-zero weight (ratioR_i = consumption *
+//           remainR != 0 exactly for them), so that pass writes their coordinates and new weights as a dense list
+//           and this one stages it with straight float4 copies (no scan, no scattered LDS stores).
+enum Var { V_PLAIN = 0, V_CULL = 1, V_CCAND = 2, V_COWN = 3, V_CLIST = 4 };
 
 // Everything a pass needs is derived from this small description of one approxmatch call: the same function
 // builds the arguments of pass p for the per-launch schedule (host) and inside the persistent kernel (device).
@@ -115,6 +122,8 @@ struct Sched {
     const float *soa1, *soa2, *box1, *box2, *box64_1, *box64_2;
     float *rem, *lv;               // sorted space: remain row = remainL(n4) | remainR ping(m4) | pong(m4); level rows
     float multiL, multiR, cut_scale;
+    float *clist;                  // dense candidate list handed from pass B to pass C/A (null: pass C/A compacts itself)
+    int *clist_cnt;
     int skip;                      // work-skipping variants enabled
     LevelConsts lc;
     int *dbg;
@@ -162,10 +171,13 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
             a.remain_out = sc.rem + sc.n4 + ((i + 1) & 1) * sc.m4;
             a.remain_stride = rs;
             a.ratio_out = ratioR; a.ratio_stride = kLevels * nm4;
+            if (var == V_COWN) { a.clist = sc.clist; a.clist_cnt = sc.clist_cnt; a.cl_n4 = sc.m4; }
             a.dbg = sc.dbg_counts ? sc.dbg + 2 + 4 * i : nullptr;
         } else {           // pass C of level i (+ pass A of level i+1)
             mode = i + 1 < kLevels ? PH_CA : PH_C;
-            var = !sc.skip ? V_PLAIN : i <= 1 ? V_CULL : V_CCAND;  // the cull radius is the one of level i+1
+            // (the cull radius is the one of level i+1); from level 3 on pass B has left the dense candidate list
+            var = !sc.skip ? V_PLAIN : i <= 1 ? V_CULL : (i == 2 || !sc.clist) ? V_CCAND : V_CLIST;
+            if (var == V_CLIST) { a.clist = sc.clist; a.clist_cnt = sc.clist_cnt; a.cl_n4 = sc.m4; }
             a.w0 = ratioR; a.w0_stride = kLevels * nm4;
             a.w1 = sc.rem + sc.n4 + ((i + 1) & 1) * sc.m4; a.w1_stride = rs;
             a.remain = sc.rem; a.remain_stride = rs;
@@ -241,8 +253,9 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     constexpr int TQ = 64 * R;
     constexpr int NW = (MODE == PH_CA) ? 2 : 1;
     constexpr bool W0_CONST = (MODE == PH_A);
-    constexpr bool CULL = VAR == V_CULL, CCAND = VAR == V_CCAND, COWN = VAR == V_COWN;
-    static_assert(!(CCAND && W0_CONST), "pass A of the first level has constant weights");
+    constexpr bool CULL = VAR == V_CULL, CCAND = VAR == V_CCAND, COWN = VAR == V_COWN, CLIST = VAR == V_CLIST;
+    static_assert(!((CCAND || CLIST) && W0_CONST), "pass A of the first level has constant weights");
+    static_assert(!(CLIST && PERSIST), "the dense candidate list is a hand-off between launches");
     static_assert(TQ <= T, "one epilogue owner per thread");
     using L = PhaseLds<2, R, S, CH>;  // offsets do not depend on NW so that every phase sees the same carve
     float *lds_c = smem;                               // x | y | z | w0 | (w1)
@@ -346,6 +359,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             atomicAdd(&a.dbg[0], a.n_own);
             atomicAdd(&a.dbg[1], a.n_own - total);
         }
+        if (a.clist_cnt && tile == 0 && tid == 0) a.clist_cnt[smp] = total;  // pass C/A stages exactly the live owners
         n_valid = min(TQ, total - lo);
         if (n_valid <= 0) return;  // wave-uniform: nothing live in this tile
         __syncthreads();
@@ -394,8 +408,15 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     const float4 *BB4 = reinterpret_cast<const float4 *>(lds_bb);
     const float c0 = a.c0, c1 = a.c1, cut2 = a.cut2;
 
-    for (int q0 = 0; q0 < a.n_cand; q0 += CH) {
-        const int cnt = min(CH, a.n_cand - q0);
+    const int n_cand = CLIST ? __builtin_amdgcn_readfirstlane(a.clist_cnt[smp]) : a.n_cand;
+    if (CLIST) {  // dense list of this sample: x | y | z | ratioR (w0) | remainR (w1), rows of cl_n4 floats
+        C = a.clist + (size_t)smp * 5 * a.cl_n4;
+        W0 = C + (size_t)3 * a.cl_n4;
+        W1 = C + (size_t)4 * a.cl_n4;
+    }
+    const int cand_pitch = CLIST ? a.cl_n4 : a.cand_n4;
+    for (int q0 = 0; q0 < n_cand; q0 += CH) {
+        const int cnt = min(CH, n_cand - q0);
         int ngroups = (cnt + 3) / 4;
         if (q0) __syncthreads();
         if (CCAND) {
@@ -456,8 +477,8 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             // all loads of a thread issued before the first LDS store
             float4 *dst4 = reinterpret_cast<float4 *>(lds_c);
             const float4 *sx = reinterpret_cast<const float4 *>(C + q0);
-            const float4 *sy = reinterpret_cast<const float4 *>(C + (size_t)a.cand_n4 + q0);
-            const float4 *sz = reinterpret_cast<const float4 *>(C + (size_t)2 * a.cand_n4 + q0);
+            const float4 *sy = reinterpret_cast<const float4 *>(C + (size_t)cand_pitch + q0);
+            const float4 *sz = reinterpret_cast<const float4 *>(C + (size_t)2 * cand_pitch + q0);
             const float *sw0 = W0_CONST ? nullptr : W0 + q0;
             const float *sw1 = NW == 2 ? W1 + q0 : nullptr;
             for (int i = tid; i < ngroups; i += T) {
@@ -465,11 +486,17 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
                 float4 v0 = make_float4(a.w0c, a.w0c, a.w0c, a.w0c), v1 = v0;
                 if (!W0_CONST) v0 = xld4<PERSIST>(sw0 + 4 * i);
                 if (NW == 2) v1 = xld4<PERSIST>(sw1 + 4 * i);
-                if (W0_CONST && i * 4 + 3 >= cnt) {  // padded candidates must weigh 0
+                if ((W0_CONST || CLIST) && i * 4 + 3 >= cnt) {  // padded candidates must weigh 0 (the list's tail is stale)
                     v0.x = i * 4 + 0 < cnt ? v0.x : 0.f;
                     v0.y = i * 4 + 1 < cnt ? v0.y : 0.f;
                     v0.z = i * 4 + 2 < cnt ? v0.z : 0.f;
                     v0.w = 0.f;
+                    if (NW == 2) {
+                        v1.x = i * 4 + 0 < cnt ? v1.x : 0.f;
+                        v1.y = i * 4 + 1 < cnt ? v1.y : 0.f;
+                        v1.z = i * 4 + 2 < cnt ? v1.z : 0.f;
+                        v1.w = 0.f;
+                    }
                 }
                 dst4[i] = vx;
                 dst4[CH / 4 + i] = vy;
@@ -568,8 +595,25 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             const float rR = a.first ? a.multiR : pre_rem;
             const float sumr = t0 * rR;
             const float consumption = __builtin_fminf(rR / (sumr + 1e-9f), 1.0f);
-            xst<PERSIST>(&a.ratio_out[(size_t)smp * a.ratio_stride + o], consumption * rR);
-            xst<PERSIST>(&a.remain_out[(size_t)smp * a.remain_stride + o], __builtin_fmaxf(0.0f, rR - sumr));
+            const float ratio_new = consumption * rR, remain_new = __builtin_fmaxf(0.0f, rR - sumr);
+            xst<PERSIST>(&a.ratio_out[(size_t)smp * a.ratio_stride + o], ratio_new);
+            xst<PERSIST>(&a.remain_out[(size_t)smp * a.remain_stride + o], remain_new);
+            if (COWN && !PERSIST && a.clist) {
+                // this owner is the (tile * TQ + e)-th live one of its sample == its place in the next pass's candidate list
+                float cx = ox[0], cy = oy[0], cz = oz[0];  // thread e = w * 64 + lane holds owner e in slot r = w
+#pragma unroll
+                for (int r = 1; r < R; r++) {
+                    cx = w == r ? ox[r] : cx;
+                    cy = w == r ? oy[r] : cy;
+                    cz = w == r ? oz[r] : cz;
+                }
+                float *cl = a.clist + (size_t)smp * 5 * a.cl_n4 + tile * TQ + e;
+                cl[0] = cx;
+                cl[(size_t)a.cl_n4] = cy;
+                cl[(size_t)2 * a.cl_n4] = cz;
+                cl[(size_t)3 * a.cl_n4] = ratio_new;
+                cl[(size_t)4 * a.cl_n4] = remain_new;
+            }
         } else {
             // pass C: suml = sum_l e*ratioL[k]*ratioR[l] ; remainL = max(0, remainL - suml)   :154-162
             float *rem = a.remain + (size_t)smp * a.remain_stride + o;
@@ -1647,6 +1691,8 @@ int launch_phase_rs(PhaseArgs a, int b, int var, hipStream_t st, const char *wha
         if (var == V_CULL) hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, V_CULL>), g, blk, 0, st, a);
         else if (var == V_CCAND && (MODE == PH_CA || MODE == PH_C))
             hipLaunchKernelGGL((am_phase_kernel<(MODE == PH_CA || MODE == PH_C) ? MODE : PH_C, R, S, kPhCH, V_CCAND>), g, blk, 0, st, a);
+        else if (var == V_CLIST && (MODE == PH_CA || MODE == PH_C))
+            hipLaunchKernelGGL((am_phase_kernel<(MODE == PH_CA || MODE == PH_C) ? MODE : PH_C, R, S, kPhCH, V_CLIST>), g, blk, 0, st, a);
         else if (var == V_COWN && MODE == PH_B)
             hipLaunchKernelGGL((am_phase_kernel<PH_B, R, S, kPhCH, V_COWN>), g, blk, 0, st, a);
         else hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, V_PLAIN>), g, blk, 0, st, a);
@@ -1723,7 +1769,7 @@ size_t cost_parts(int n, int m) { return (size_t)pcc::ceil_div(n, kMatKT) * pcc:
 // Workspace carve (bytes, every section 16-byte aligned).
 struct WsLayout {
     int n4, m4, nb1, nb2, nb64_1, nb64_2;
-    size_t soa1, soa2, rank1, rank2, box1, box2, box64_1, box64_2, rem, lv, lv_orig, cpart, sync, total;
+    size_t soa1, soa2, rank1, rank2, box1, box2, box64_1, box64_2, rem, lv, lv_orig, cpart, sync, clist, clist_cnt, total;
     WsLayout(int b, int n, int m) {
         auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
         n4 = (n + 3) & ~3;
@@ -1746,6 +1792,8 @@ struct WsLayout {
         lv_orig = o; o = up(o + (size_t)b * kLevels * ((size_t)n + m) * 4);
         cpart = o; o = up(o + (size_t)b * cost_parts(n, m) * 4);
         sync = o; o = up(o + ((size_t)b + 1) * 4);   // per-sample barrier counters + error word (persistent kernel)
+        clist = o; o = up(o + (size_t)b * 5 * m4 * 4);   // dense candidate list handed from pass B to pass C/A
+        clist_cnt = o; o = up(o + (size_t)b * 4);
         total = o;
     }
 };
@@ -1864,6 +1912,14 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
     }();
     const int group = resident > 0 ? resident / tiles : 0;  // samples per persistent launch
     const bool use_persist = persist_mode == 1 && group >= 1;
+    static const bool clist_enabled = [] {  // PCC_AM_NOCLIST=1: pass C/A compacts its candidates itself (A/B measurements)
+        const char *e = std::getenv("PCC_AM_NOCLIST");
+        return !(e && e[0] == '1');
+    }();
+    if (!use_persist && clist_enabled) {
+        sc.clist = reinterpret_cast<float *>(base + L.clist);
+        sc.clist_cnt = reinterpret_cast<int *>(base + L.clist_cnt);
+    }
     if (use_persist) {
         unsigned *counters = reinterpret_cast<unsigned *>(base + L.sync);
         if (hipMemsetAsync(counters, 0, ((size_t)b + 1) * sizeof(unsigned), st) != hipSuccess)
