@@ -169,6 +169,49 @@ def NNDistance(set_d: torch.Tensor, set_q: torch.Tensor) -> list[torch.Tensor]:
     return [dist1, idx1, dist2, idx2]
 
 
+def ChamferLoss(set_d: torch.Tensor, set_q: torch.Tensor, mean: bool) -> list[torch.Tensor]:
+    """NNDistance + the loss reduction in one call (extension, ``pcc_chamfer_loss``):
+    -> [loss[B], dist1, idx1, dist2, idx2] with loss = mean_j dist1 + mean_k dist2 (``mean``) or the sums."""
+    b, n, m = _sizes(set_d, set_q)
+    dev = set_d.device
+    loss = torch.empty((b,), dtype=torch.float32, device=dev)
+    dist1 = torch.empty((b, n), dtype=torch.float32, device=dev)
+    idx1 = torch.empty((b, n), dtype=torch.int32, device=dev)
+    dist2 = torch.empty((b, m), dtype=torch.float32, device=dev)
+    idx2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+    _check_input(set_d, 'set_d')
+    _check_input(set_q, 'set_q')
+    _f32(set_d, 'set_d')
+    _f32(set_q, 'set_q')
+    with torch.cuda.device(dev):
+        _lib.check(_L.pcc_chamfer_loss(b, n, set_d.data_ptr(), m, set_q.data_ptr(), int(mean), loss.data_ptr(),
+                                       dist1.data_ptr(), idx1.data_ptr(), dist2.data_ptr(), idx2.data_ptr(),
+                                       _stream(set_d)), 'ChamferLoss')
+    return [loss, dist1, idx1, dist2, idx2]
+
+
+def ChamferLossGrad(set_d: torch.Tensor, set_q: torch.Tensor, idx1: torch.Tensor, idx2: torch.Tensor,
+                    grad_loss: torch.Tensor, mean: bool) -> list[torch.Tensor]:
+    """NNDistanceGrad with ``grad_dist1[b,:] = grad_loss[b] (/N)``, ``grad_dist2[b,:] = grad_loss[b] (/M)`` formed
+    inside the kernel (extension, ``pcc_chamfer_loss_grad``) -> [grad1[B,N,3], grad2[B,M,3]]."""
+    b, n, m = _sizes(set_d, set_q)
+    grad1 = torch.empty((b, n, 3), dtype=torch.float32, device=set_d.device)
+    grad2 = torch.empty((b, m, 3), dtype=torch.float32, device=set_d.device)
+    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (idx1, 'idx1'), (idx2, 'idx2'), (grad_loss, 'grad_loss')):
+        _check_input(t, name)
+    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (grad_loss, 'grad_loss')):
+        _f32(t, name)
+    _i32(idx1, 'idx1')
+    _i32(idx2, 'idx2')
+    if idx1.numel() != b * n or idx2.numel() != b * m or grad_loss.numel() != b:
+        raise RuntimeError('ChamferLossGrad: idx / grad_loss shapes do not match the clouds')
+    with torch.cuda.device(set_d.device):
+        _lib.check(_L.pcc_chamfer_loss_grad(b, n, set_d.data_ptr(), m, set_q.data_ptr(), idx1.data_ptr(),
+                                            idx2.data_ptr(), grad_loss.data_ptr(), int(mean), grad1.data_ptr(),
+                                            grad2.data_ptr(), _stream(set_d)), 'ChamferLossGrad')
+    return [grad1, grad2]
+
+
 def NNDistanceGrad(set_d: torch.Tensor, set_q: torch.Tensor, idx1: torch.Tensor, idx2: torch.Tensor,
                    grad_dist1: torch.Tensor, grad_dist2: torch.Tensor) -> list[torch.Tensor]:
     """-> [grad1[B,N,3], grad2[B,M,3]]   (structural_loss.cpp:102-125)."""

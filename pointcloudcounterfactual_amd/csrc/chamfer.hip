@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *_
                                                             const float *__restrict__ gd2,
                                                             const int *__restrict__ idx2,
                                                             float *__restrict__ grad1, float *__restrict__ grad2,
-                                                            int P) {
+                                                            int P, const float *__restrict__ gloss, int mean) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const int smp = blockIdx.y, p = blockIdx.x;
     const int tid = threadIdx.x, T = 256;
@@ -203,18 +203,22 @@ __global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *_
     const float *p2 = xyz2 + (size_t)smp * m * 3;
     const int *i1 = idx1 + (size_t)smp * n;
     const int *i2 = idx2 + (size_t)smp * m;
-    const float *g1 = gd1 + (size_t)smp * n;
-    const float *g2 = gd2 + (size_t)smp * m;
+    // upstream gradient: per point (nn_distance backward) or, for the fused Chamfer loss, one scalar per sample
+    // spread over the points (loss = sum or mean of the distances)
+    const float *g1 = gloss ? nullptr : gd1 + (size_t)smp * n;
+    const float *g2 = gloss ? nullptr : gd2 + (size_t)smp * m;
+    const float gs = gloss ? gloss[smp] : 0.f;
+    const float gs1 = mean ? gs / (float)n : gs, gs2 = mean ? gs / (float)m : gs;
     // direct terms (one owner per destination -> plain LDS stores)
     for (int j = j0 + tid; j < j1; j += T) {
         const int j2 = i1[j];
-        const float g = g1[j] * 2;
+        const float g = (gloss ? gs1 : g1[j]) * 2;
 #pragma unroll
         for (int c = 0; c < 3; c++) acc1[(j - j0) * 3 + c] = g * (p1[j * 3 + c] - p2[j2 * 3 + c]);
     }
     for (int k = k0 + tid; k < k1; k += T) {
         const int k2 = i2[k];
-        const float g = g2[k] * 2;
+        const float g = (gloss ? gs2 : g2[k]) * 2;
 #pragma unroll
         for (int c = 0; c < 3; c++) acc2[(k - k0) * 3 + c] = g * (p2[k * 3 + c] - p1[k2 * 3 + c]);
     }
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *_
     for (int k = tid; k < m; k += T) {
         const int j = i2[k];
         if (j >= j0 && j < j1) {
-            const float g = g2[k] * 2;
+            const float g = (gloss ? gs2 : g2[k]) * 2;
 #pragma unroll
             for (int c = 0; c < 3; c++) atomicAdd(&acc1[(j - j0) * 3 + c], -(g * (p2[k * 3 + c] - p1[j * 3 + c])));
         }
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *_
     for (int j = tid; j < n; j += T) {
         const int k = i1[j];
         if (k >= k0 && k < k1) {
-            const float g = g1[j] * 2;
+            const float g = (gloss ? gs1 : g1[j]) * 2;
 #pragma unroll
             for (int c = 0; c < 3; c++) atomicAdd(&acc2[(k - k0) * 3 + c], -(g * (p1[j * 3 + c] - p2[k * 3 + c])));
         }
@@ -241,6 +245,48 @@ __global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *_
     float *o2 = grad2 + ((size_t)smp * m + k0) * 3;
     for (int i = tid; i < (j1 - j0) * 3; i += T) o1[i] = acc1[i];
     for (int i = tid; i < (k1 - k0) * 3; i += T) o2[i] = acc2[i];
+}
+
+// loss[b] = sum_j dist1[b,j] (/ n) + sum_k dist2[b,k] (/ m): the reduction of the Chamfer loss
+// (pykeops_chamfer: mean, metrics_and_losses.py:38-41; torch_chamfer: sum, :46-47), one workgroup per sample,
+// fixed-order tree (deterministic).
+__global__ __launch_bounds__(256) void chamfer_reduce_kernel(int n, int m, const float *__restrict__ dist1,
+                                                              const float *__restrict__ dist2, int mean,
+                                                              float *__restrict__ loss) {
+    __shared__ float red[2][256];
+    const int smp = blockIdx.x, tid = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < n; i += 256) s1 += dist1[(size_t)smp * n + i];
+    for (int i = tid; i < m; i += 256) s2 += dist2[(size_t)smp * m + i];
+    red[0][tid] = s1;
+    red[1][tid] = s2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            red[0][tid] += red[0][tid + off];
+            red[1][tid] += red[1][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) loss[smp] = mean ? red[1][0] / (float)m + red[0][0] / (float)n : red[0][0] + red[1][0];
+}
+
+int launch_bwd(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad_dist1, const int *idx1,
+               const float *grad_dist2, const int *idx2, const float *gloss, int mean, float *grad_xyz1,
+               float *grad_xyz2, hipStream_t st) {
+    // P destination ranges per sample: ~512 workgroups on the chip, each range pair <= 48 KiB of LDS.
+    long long P = std::max<long long>(1, pcc::ceil_div(512, b));
+    P = std::min<long long>(P, std::max(1, std::min(n, m) / 64));
+    const long long lds_min = ((long long)n + m) * 12 / (48 * 1024) + 1;
+    P = std::max(P, lds_min);
+    if (P > 65535) return pcc::invalid("nndistancegrad: clouds too large");
+    const size_t lds = ((size_t)pcc::ceil_div(n, (int)P) + pcc::ceil_div(m, (int)P) + 2) * 3 * sizeof(float);
+    {
+        pcc::ProfScope prof("nn_bwd_range_kernel", st);
+        hipLaunchKernelGGL(nn_bwd_range_kernel, dim3((unsigned)P, (unsigned)b), dim3(256), lds, st, n, xyz1, m, xyz2,
+                           grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, (int)P, gloss, mean);
+    }
+    return pcc::check_launch("nndistancegrad");
 }
 
 template <int R, int S>
@@ -303,20 +349,30 @@ int pcc_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2
     if (n == 0 || m == 0) return pcc::invalid("nndistancegrad: one cloud is empty");
     if (!xyz1 || !xyz2 || !grad_dist1 || !idx1 || !grad_dist2 || !idx2 || !grad_xyz1 || !grad_xyz2)
         return pcc::invalid("nndistancegrad: null pointer");
+    return launch_bwd(b, n, xyz1, m, xyz2, grad_dist1, idx1, grad_dist2, idx2, nullptr, 0, grad_xyz1, grad_xyz2,
+                      static_cast<hipStream_t>(stream));
+}
+
+int pcc_chamfer_loss(int b, int n, const float *xyz1, int m, const float *xyz2, int mean, float *loss, float *dist1,
+                     int *idx1, float *dist2, int *idx2, pcc_stream_t stream) {
+    if (int rc = pcc_nndistance(b, n, xyz1, m, xyz2, dist1, idx1, dist2, idx2, stream)) return rc;
+    if (b == 0) return PCC_OK;
+    if (!loss) return pcc::invalid("chamfer_loss: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // P destination ranges per sample: ~512 workgroups on the chip, each range pair <= 48 KiB of LDS.
-    long long P = std::max<long long>(1, pcc::ceil_div(512, b));
-    P = std::min<long long>(P, std::max(1, std::min(n, m) / 64));
-    const long long lds_min = ((long long)n + m) * 12 / (48 * 1024) + 1;
-    P = std::max(P, lds_min);
-    if (P > 65535) return pcc::invalid("nndistancegrad: clouds too large");
-    const size_t lds = ((size_t)pcc::ceil_div(n, (int)P) + pcc::ceil_div(m, (int)P) + 2) * 3 * sizeof(float);
-    {
-        pcc::ProfScope prof("nn_bwd_range_kernel", st);
-        hipLaunchKernelGGL(nn_bwd_range_kernel, dim3((unsigned)P, (unsigned)b), dim3(256), lds, st, n, xyz1, m, xyz2,
-                           grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, (int)P);
-    }
-    return pcc::check_launch("nndistancegrad");
+    hipLaunchKernelGGL(chamfer_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, n, m, dist1, dist2, mean, loss);
+    return pcc::check_launch("chamfer_loss(reduce)");
+}
+
+int pcc_chamfer_loss_grad(int b, int n, const float *xyz1, int m, const float *xyz2, const int *idx1, const int *idx2,
+                          const float *grad_loss, int mean, float *grad_xyz1, float *grad_xyz2, pcc_stream_t stream) {
+    pcc::clear_error();
+    if (b < 0 || n < 0 || m < 0) return pcc::invalid("chamfer_loss_grad: negative size");
+    if (b == 0 || (n == 0 && m == 0)) return PCC_OK;
+    if (n == 0 || m == 0) return pcc::invalid("chamfer_loss_grad: one cloud is empty");
+    if (!xyz1 || !xyz2 || !idx1 || !idx2 || !grad_loss || !grad_xyz1 || !grad_xyz2)
+        return pcc::invalid("chamfer_loss_grad: null pointer");
+    return launch_bwd(b, n, xyz1, m, xyz2, nullptr, idx1, nullptr, idx2, grad_loss, mean, grad_xyz1, grad_xyz2,
+                      static_cast<hipStream_t>(stream));
 }
 
 void nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad_dist1,

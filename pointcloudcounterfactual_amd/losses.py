@@ -82,7 +82,8 @@ class MatchCostFunction(Function):
         if ctx.mode == 'implicit':
             grad1, grad2 = ctx.saved_tensors
             scale = grad_output.unsqueeze(1).unsqueeze(2)
-            return grad1 * scale, grad2 * scale
+            return (grad1 * scale if ctx.needs_input_grad[0] else None,
+                    grad2 * scale if ctx.needs_input_grad[1] else None)
         set1, set2 = ctx.saved_tensors
         if ctx.mode == 'fused':  # upstream gradient folded into the reduction of the gradient kernel
             grad1, grad2 = backend.MatchCostGradScaled(set1, set2, ctx.match, grad_output.contiguous().float())
@@ -100,19 +101,38 @@ nn_distance = NNDistanceFunction.apply
 match_cost = MatchCostFunction.apply
 
 
+class ChamferFunction(Function):
+    """``(t1[B,N,3], t2[B,M,3], mean) -> loss[B]``: nearest-neighbour search, loss reduction and -- in backward --
+    the spreading of ``grad_loss[b]`` over the points, all inside the library (two launches forward, one backward)
+    instead of six small elementwise / reduction launches around ``nn_distance``."""
+
+    @staticmethod
+    def forward(ctx: Any, *args: Any, **kwargs: Any) -> torch.Tensor:
+        t1, t2, mean = args
+        loss, _d1, idx1, _d2, idx2 = backend.ChamferLoss(t1, t2, bool(mean))
+        ctx.save_for_backward(t1, t2, idx1, idx2)  # indices are constants of the backward pass
+        ctx.mean = bool(mean)
+        return loss
+
+    @staticmethod
+    def backward(ctx: Any, *grad_outputs: Any) -> Any:
+        t1, t2, idx1, idx2 = ctx.saved_tensors
+        grad1, grad2 = backend.ChamferLossGrad(t1, t2, idx1, idx2, grad_outputs[0].contiguous().float(), ctx.mean)
+        return grad1, grad2, None
+
+
 def chamfer(t1: torch.Tensor, t2: torch.Tensor, reduction: str = 'mean') -> torch.Tensor:
     """Chamfer loss ``[B]`` on the accelerator.
 
     ``reduction='mean'`` reproduces ``pykeops_chamfer`` (metrics_and_losses.py:21-41):
     ``dist2.mean(1) + dist1.mean(1)``; ``'sum'`` reproduces the scale of ``torch_chamfer`` (:44-47).
     Gradients flow through the gathered nearest neighbours only (indices are constants), as in both.
+    Equal to the same expression written with ``nn_distance`` (tests/test_gpu_structural.py) up to the order of
+    the float sums.
     """
-    dist1, dist2 = nn_distance(t1, t2)
-    if reduction == 'mean':
-        return dist2.mean(1) + dist1.mean(1)
-    if reduction == 'sum':
-        return dist1.sum(1) + dist2.sum(1)
-    raise ValueError(f"reduction must be 'mean' or 'sum', got {reduction!r}")
+    if reduction not in ('mean', 'sum'):
+        raise ValueError(f"reduction must be 'mean' or 'sum', got {reduction!r}")
+    return ChamferFunction.apply(t1, t2, reduction == 'mean')
 
 
 def torch_square_distance(t1: torch.Tensor, t2: torch.Tensor) -> torch.Tensor:

@@ -400,3 +400,28 @@ def test_implicit_match_cost_bit_reproducible(cuda):
     for _ in range(3):
         r2 = backend.MatchCostImplicit(t1, t2, True)
         assert all(torch.equal(x, y) for x, y in zip(r1, r2))
+
+
+@pytest.mark.parametrize('reduction', ['mean', 'sum'])
+@pytest.mark.parametrize('b,n,m', [(2, 3, 5), (3, 257, 130), (2, 2048, 2048)])
+def test_chamfer_fused_equals_nn_distance_expression(cuda, b, n, m, reduction):
+    """chamfer() (pcc_chamfer_loss / pcc_chamfer_loss_grad: reductions inside the library) == the same loss written
+    with nn_distance and torch reductions (pykeops_chamfer / torch_chamfer shape, metrics_and_losses.py:21-47)."""
+    from pointcloudcounterfactual_amd.losses import chamfer, nn_distance
+
+    a, c = pair(55 + n, b, n, m)
+    w = torch.linspace(-1.0, 2.0, b, device=cuda)
+    t1 = _dev(a, cuda).requires_grad_(True)
+    t2 = _dev(c, cuda).requires_grad_(True)
+    loss = chamfer(t1, t2, reduction)
+    (loss * w).sum().backward()
+    u1 = _dev(a, cuda).requires_grad_(True)
+    u2 = _dev(c, cuda).requires_grad_(True)
+    d1, d2 = nn_distance(u1, u2)
+    ref = d2.mean(1) + d1.mean(1) if reduction == 'mean' else d1.sum(1) + d2.sum(1)
+    (ref * w).sum().backward()
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(t1.grad.cpu().numpy(), u1.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(t2.grad.cpu().numpy(), u2.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        chamfer(t1, t2, 'max')
