@@ -36,6 +36,7 @@ SEED = 1234 + 2  # seed = 1234 + config id
 # 8 flop for the squared distance + level multiply + weight multiply + accumulate + 1 for the exp
 # = 12 flop + 1 exp, counted as 13.
 FLOP_PER_PAIR_PASS = 13.0
+PHASE_LAUNCHES = 19        # am_phase_kernel launches per approxmatch (27 reference passes, 8 of them fused pairwise)
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector peak == FP32 dense MFMA peak
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
 CHAMFER_ALGO_BYTES = 6_815_744  # fwd 2,621,440 + bwd 4,194,304 at B=32, N=M=2048
@@ -113,16 +114,14 @@ def kernel_breakdown(recon_t, ref_t, steps: int) -> dict[str, float]:
 
 
 def phase_kernel_time_us(recon_t, ref_t, steps: int) -> tuple[float, int]:
-    """Average duration of ONE am_phase_kernel launch (the dominant kernel), HIP events around the
-    20-launch approxmatch sequence minus the materialise launch, divided by the 19 phase launches.
-    The library's own per-launch instrumentation (pcc_profile_*) brackets each phase launch with
-    hipEvents on the launch stream."""
+    """Average duration of ONE am_phase_kernel launch (the dominant kernel), measured live with HIP events on
+    the launch stream: the library brackets the 19 back-to-back phase launches of every approxmatch with one event
+    before the first and one after the last (pcc_profile_enable(2); no event between the kernels, so nothing but
+    the kernels themselves is in the interval) and the interval is divided by 19."""
     from pointcloudcounterfactual_amd import _lib, backend
 
     L = _lib.lib
-    if not hasattr(L, 'pcc_profile_enable'):
-        return float('nan'), 0
-    L.pcc_profile_enable(1)
+    L.pcc_profile_enable(2)
     for _ in range(steps):
         backend.MatchCostImplicit(recon_t, ref_t, True)
     torch.cuda.synchronize()
@@ -130,9 +129,9 @@ def phase_kernel_time_us(recon_t, ref_t, steps: int) -> tuple[float, int]:
 
     us = ctypes.c_double(0)
     cnt = ctypes.c_int(0)
-    L.pcc_profile_read(b'am_phase_kernel', ctypes.byref(us), ctypes.byref(cnt))
+    L.pcc_profile_read(b'am_phase_sequence', ctypes.byref(us), ctypes.byref(cnt))
     L.pcc_profile_enable(0)
-    return us.value, cnt.value
+    return us.value / PHASE_LAUNCHES, cnt.value * PHASE_LAUNCHES
 
 
 def cpu_baseline(recon: np.ndarray, ref: np.ndarray, clouds: int) -> dict:
@@ -257,7 +256,7 @@ def main() -> None:
         pairs = B_PER_GPU * N_POINTS * N_POINTS
         # The dominant kernel: am_phase_kernel (19 launches per approxmatch, ~75% of the step).  Of the 27
         # reference passes, 27 are covered by those 19 launches (8 launches fuse pass C with the next pass A).
-        algo_flop_per_launch = 27.0 / 19.0 * pairs * FLOP_PER_PAIR_PASS
+        algo_flop_per_launch = 27.0 / PHASE_LAUNCHES * pairs * FLOP_PER_PAIR_PASS
         achieved = algo_flop_per_launch / (phase_us * 1e-6) / 1e12 if phase_us == phase_us and phase_us > 0 else None
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')

@@ -41,11 +41,14 @@ const char *pcc_last_error(void);
 int pcc_last_status(void);
 
 /* ---- per-kernel timing (measurement aid, off by default) ----------------------------------------
- * When enabled, every kernel launch of this library is bracketed by two hipEvents recorded on the
- * launch stream.  pcc_profile_read synchronises on the recorded events and returns the average
- * duration (microseconds) and the number of launches whose kernel name starts with `kernel_prefix`
- * since the last pcc_profile_enable(1) / pcc_profile_reset().  Returns 0, or PCC_EINVAL if nothing
- * matched.  Not thread-safe against concurrent launches; meant for bench.py. */
+ * pcc_profile_enable(1): every kernel launch of this library is bracketed by two hipEvents recorded on the
+ * launch stream.  pcc_profile_enable(2): only whole launch SEQUENCES are bracketed (one event before the first
+ * launch, one after the last; name "am_phase_sequence" = the 19 back-to-back am_phase_kernel launches of one
+ * approxmatch) -- no event sits between the kernels, so sequence / launches is the per-launch duration a kernel
+ * trace reports.  pcc_profile_enable(0): off.  pcc_profile_read synchronises on the recorded events and returns the
+ * average duration (microseconds) and the number of recorded scopes whose name starts with `kernel_prefix` since the
+ * last enable / pcc_profile_reset().  Returns 0, or PCC_EINVAL if nothing matched.  Not thread-safe against
+ * concurrent launches; meant for bench.py. */
 void pcc_profile_enable(int on);
 void pcc_profile_reset(void);
 int pcc_profile_read(const char *kernel_prefix, double *avg_us, int *launches);

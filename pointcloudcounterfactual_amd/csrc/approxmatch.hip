@@ -1933,6 +1933,7 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         rc = pcc::check_launch("approxmatch(persistent)");
         if (rc) return rc;
     } else {
+        pcc::ProfScope seq("am_phase_sequence", st, true);
         for (int p = 0; p < sched_phases(); p++) {
             int mode, var;
             const PhaseArgs a = build_phase(sc, p, &mode, &var);

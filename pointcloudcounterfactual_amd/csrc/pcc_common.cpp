@@ -26,7 +26,7 @@ struct ProfRec {
     const char *name;
     hipEvent_t a, b;
 };
-bool g_prof_on = false;
+int g_prof_mode = 0;  // 0 off, 1 every kernel launch, 2 only the coarse scopes (launch sequences)
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 void prof_clear() {
@@ -38,9 +38,9 @@ void prof_clear() {
 }
 }  // namespace
 
-bool profiling() { return g_prof_on; }
-ProfScope::ProfScope(const char *kernel, hipStream_t s) : st(s), name(kernel) {
-    if (!g_prof_on) return;
+bool profiling() { return g_prof_mode != 0; }
+ProfScope::ProfScope(const char *kernel, hipStream_t s, bool coarse) : st(s), name(kernel) {
+    if (g_prof_mode != (coarse ? 2 : 1)) return;
     if (hipEventCreate(&start) != hipSuccess) {
         start = nullptr;
         return;
@@ -63,7 +63,7 @@ ProfScope::~ProfScope() {
 extern "C" {
 void pcc_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(pcc::g_prof_mu);
-    pcc::g_prof_on = on != 0;
+    pcc::g_prof_mode = on;
     if (on) pcc::prof_clear();
 }
 void pcc_profile_reset(void) {

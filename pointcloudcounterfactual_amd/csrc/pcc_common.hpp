@@ -44,7 +44,8 @@ struct ProfScope {
     hipEvent_t start = nullptr;
     hipStream_t st;
     const char *name;
-    ProfScope(const char *kernel, hipStream_t s);
+    // coarse scopes bracket a whole launch sequence and are recorded only in mode 2 (no per-launch events inside)
+    ProfScope(const char *kernel, hipStream_t s, bool coarse = false);
     ~ProfScope();
 };
 
