@@ -76,6 +76,20 @@ int pcc_neighbour_minmax_target(int b, int c, int n, int k, const float *y, cons
 int pcc_global_pool(int b, int c, int n, const float *x, float *out_max, int32_t *argmax, float *out_mean,
                     pcc_stream_t stream);
 
+/* ---- generic-dimension pairwise reductions (the KeOps reductions of the reference outside the 3-D paths) ----------
+ * D[b,i,j] = sum_c (p[b,i,c] - q[b,j,c])^2 over p[b,np,d], q[b,nq,d] (pykeops_square_distance, neighbour_ops.py:35-40),
+ * difference form, channels accumulated in order with fma; never materialised.
+ * pcc_pair_argmin: idx[b,i] = argmin_j D[b,i,j] (lowest index on ties), dist[b,i] = the minimum (may be NULL) --
+ *   VectorQuantizer.quantize's `dist.argmin(axis=2)` (src/module/quantize.py:26-28); swap p and q for axis=1.
+ * pcc_pair_sqdist_sum: out[b,i] = sum_j D[b,i,j] -- `dist.sum(1)` of quantize.py:31 (with p = codebook rows, q = the
+ *   single query); pcc_pair_sqdist_sum_bwd: its gradients, grad_p[b,i,:] = 2 g[b,i] sum_j (p_i - q_j),
+ *   grad_q[b,j,:] = -2 sum_i g[b,i] (p_i - q_j); either output may be NULL. */
+int pcc_pair_argmin(int b, int np, int nq, int d, const float *p, const float *q, int64_t *idx, float *dist,
+                    pcc_stream_t stream);
+int pcc_pair_sqdist_sum(int b, int np, int nq, int d, const float *p, const float *q, float *out, pcc_stream_t stream);
+int pcc_pair_sqdist_sum_bwd(int b, int np, int nq, int d, const float *p, const float *q, const float *grad_out,
+                            float *grad_p, float *grad_q, pcc_stream_t stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -129,3 +129,64 @@ print("ok")
 '''
     r = subprocess.run(['python', '-c', code], capture_output=True, text=True)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
+def test_pykeops_shim_host_logic():
+    """The drop-in ``pykeops`` package: expression shapes, role inference and error behaviour (no compute on CPU)."""
+    import pykeops
+    from pykeops.torch import LazyTensor
+
+    from pointcloudcounterfactual_amd.keops_shim import SquareDistance
+
+    pykeops.set_verbose(False)
+    t1, t2 = torch.zeros(2, 5, 3), torch.zeros(2, 7, 3)
+    dist = ((LazyTensor(t1[:, :, None, :]) - LazyTensor(t2[:, None, :, :])) ** 2).sum(-1)  # neighbour_ops.py:37-39
+    assert isinstance(dist, SquareDistance) and dist.shape == (2, 5, 7)
+    rev = ((LazyTensor(t2[:, None, :, :]) - LazyTensor(t1[:, :, None, :])) ** 2).sum(-1)
+    assert rev.shape == (2, 5, 7)
+    # quantize.py:22-26: a one-point cloud [B,1,1,D] against a codebook [B,1,K,D]
+    q = ((LazyTensor(torch.zeros(4, 1, 4)[:, :, None, :]) - LazyTensor(torch.zeros(4, 16, 4)[:, None, :, :])) ** 2).sum(-1)
+    assert q.shape == (4, 1, 16)
+    for bad in (lambda: dist.argmin(axis=2), lambda: dist.sum(1), lambda: dist.argKmin(3, dim=2)):
+        with pytest.raises((RuntimeError, NotImplementedError)):
+            bad()  # CPU tensors: the reference never reaches PyKeOps off the accelerator
+    with pytest.raises(NotImplementedError):
+        (LazyTensor(t1[:, :, None, :]) - LazyTensor(t2[:, None, :, :])) ** 3
+    with pytest.raises(NotImplementedError):
+        LazyTensor(torch.zeros(2, 5, 7, 3))
+    with pytest.raises(NotImplementedError):
+        LazyTensor(t1[:, :, None, :]) - LazyTensor(t1[:, :, None, :])
+    with pytest.raises(NotImplementedError):
+        dist.argmin(axis=0)
+
+
+REF_NOPS = '/root/reference/src/utils/neighbour_ops.py'
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not os.path.isfile(REF_NOPS), reason='reference tree only exists in the build container')
+def test_reference_neighbour_ops_binds_our_pykeops():
+    """Boundary conformance: the reference's UNMODIFIED src/utils/neighbour_ops.py imports our ``pykeops`` drop-in and
+    its pykeops_square_distance builds our lazy distance (reductions need the accelerator)."""
+    code = f'''
+import sys, importlib.util
+sys.path.insert(0, {ROOT!r})
+spec = importlib.util.spec_from_file_location("ref_neighbour_ops", {REF_NOPS!r})
+mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+import pykeops, torch
+assert pykeops.__file__.startswith({ROOT!r})
+from pointcloudcounterfactual_amd.keops_shim import SquareDistance, LazyTensor
+assert mod.LazyTensor is LazyTensor
+d = mod.pykeops_square_distance(torch.zeros(2, 6, 3), torch.zeros(2, 9, 3))
+assert isinstance(d, SquareDistance) and d.shape == (2, 6, 9)
+try:
+    d.argmin(axis=2)
+except RuntimeError as e:
+    assert "must be a CUDA tensor" in str(e), e
+else:
+    raise SystemExit("reduction ran on CPU tensors")
+assert mod.knn(torch.zeros(1, 3, 8), 2).shape == (1, 8, 2)   # CPU tensors take the reference's torch path
+print("ok")
+'''
+    r = subprocess.run(['python', '-c', code], capture_output=True, text=True)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
