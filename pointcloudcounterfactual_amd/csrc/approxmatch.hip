@@ -1525,38 +1525,44 @@ __global__ __launch_bounds__(256) void am_pair_kernel(PairArgs a) {
             if (mask) {
                 const float4 A = lds_l[li][0], B = lds_l[li][1], Cc = lds_l[li][2];
                 const float rr[kLevels] = {A.w, B.x, B.y, B.z, B.w, Cc.x, Cc.y, Cc.z, Cc.w};
-                float d[Q], acc[Q];
+                float ex[Q], ey[Q], ez[Q], d[Q], acc[Q];
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
-                    d[q] = sq3(A.x - x1[q], A.y - y1[q], A.z - z1[q]);
+                    ex[q] = A.x - x1[q];  // p2 - p1 (approxmatch.cu:148-150)
+                    ey[q] = A.y - y1[q];
+                    ez[q] = A.z - z1[q];
+                    d[q] = sq3(ex[q], ey[q], ez[q]);
                     acc[q] = 0.f;
                 }
 #pragma unroll
                 for (int i = 0; i < kLevels; i++) {
                     if (mask & (1 << i)) {
+                        // w = exp(level d2) ratioL ratioR; match += w (approxmatch.cu:153-155): the product is added
+                        // with one fma (the contraction a compiler applies to `match += a * b`); am_materialise_kernel
+                        // rounds the product first -- the two differ by half an ulp of the product
 #pragma unroll
-                        for (int q = 0; q < Q; q++) acc[q] += (fast_exp2(a.lc.c[i] * d[q]) * rl[i][q]) * rr[i];
+                        for (int q = 0; q < Q; q++)
+                            acc[q] = __builtin_fmaf(fast_exp2(a.lc.c[i] * d[q]) * rl[i][q], rr[i], acc[q]);
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < Q; q++) {
                     if (GRAD) {
-                        // grad1 uses (p1 - p2) (approxmatch.cu:281-284); grad2 the negated vector (:240-246)
-                        const float dx = x1[q] - A.x, dy = y1[q] - A.y, dz = z1[q] - A.z;
                         // max(d2, 1e-20): d2 is never NaN, so the bare instruction (no canonicalising pre-pass)
                         float dm;
                         asm("v_max_f32 %0, %1, %2" : "=v"(dm) : "v"(d[q]), "v"(1e-20f));
-                        const float rs = __builtin_amdgcn_rsqf(dm);
-                        const float f = acc[q] * rs;
+                        const float f = acc[q] * __builtin_amdgcn_rsqf(dm);
                         // sqrt(d2) = d2 * rsqrt(d2): one transcendental serves both sums (d2 < 1e-20 moves the cost by < 1e-10)
                         csum = __builtin_fmaf(f, d[q], csum);
-                        const float tx = dx * f, ty = dy * f, tz = dz * f;
-                        g1[q][0] += tx;
-                        g1[q][1] += ty;
-                        g1[q][2] += tz;
-                        rx -= tx;
-                        ry -= ty;
-                        rz -= tz;
+                        // t = (p2 - p1) match / |p1 - p2|: grad2 (rows) accumulates +t (approxmatch.cu:240-246), grad1
+                        // (columns) the negated vector (:281-284)
+                        const float tx = ex[q] * f, ty = ey[q] * f, tz = ez[q] * f;
+                        g1[q][0] -= tx;
+                        g1[q][1] -= ty;
+                        g1[q][2] -= tz;
+                        rx += tx;
+                        ry += ty;
+                        rz += tz;
                     } else {
                         csum = __builtin_fmaf(acc[q], __builtin_amdgcn_sqrtf(d[q]), csum);
                     }
