@@ -113,11 +113,13 @@ def kernel_breakdown(recon_t, ref_t, steps: int) -> dict[str, float]:
     return {k: kt.avg_us(k) for k in kt.records}
 
 
-def phase_kernel_time_us(recon_t, ref_t, steps: int) -> tuple[float, int]:
+def phase_kernel_time_us(recon_t, ref_t, steps: int) -> tuple[float, int, int]:
     """Average duration of ONE am_phase_kernel launch (the dominant kernel), measured live with HIP events on
     the launch stream: the library brackets the 19 back-to-back phase launches of every approxmatch with one event
     before the first and one after the last (pcc_profile_enable(2); no event between the kernels, so nothing but
-    the kernels themselves is in the interval) and the interval is divided by 19."""
+    the kernels themselves is in the interval) and the interval is divided by 19.  A large batch runs as two
+    half-batch sequences on two streams at the same time: both are bracketed, each on its own stream.
+    Returns (us per launch, launches timed, concurrent sequences per call)."""
     from pointcloudcounterfactual_amd import _lib, backend
 
     L = _lib.lib
@@ -131,7 +133,7 @@ def phase_kernel_time_us(recon_t, ref_t, steps: int) -> tuple[float, int]:
     cnt = ctypes.c_int(0)
     L.pcc_profile_read(b'am_phase_sequence', ctypes.byref(us), ctypes.byref(cnt))
     L.pcc_profile_enable(0)
-    return us.value / PHASE_LAUNCHES, cnt.value * PHASE_LAUNCHES
+    return us.value / PHASE_LAUNCHES, cnt.value * PHASE_LAUNCHES, max(1, cnt.value // steps)
 
 
 def cpu_baseline(recon: np.ndarray, ref: np.ndarray, clouds: int) -> dict:
@@ -252,12 +254,14 @@ def main() -> None:
             MatchCostFunction.mode = args.emd_mode
         with torch.no_grad():
             br = kernel_breakdown(recon_t.detach(), ref_t, max(3, min(args.steps, 20)))
-            phase_us, phase_cnt = phase_kernel_time_us(recon_t.detach(), ref_t, max(3, min(args.steps, 20)))
+            phase_us, phase_cnt, lanes = phase_kernel_time_us(recon_t.detach(), ref_t, max(3, min(args.steps, 20)))
         pairs = B_PER_GPU * N_POINTS * N_POINTS
         # The dominant kernel: am_phase_kernel (19 launches per approxmatch, ~75% of the step).  Of the 27
         # reference passes, 27 are covered by those 19 launches (8 launches fuse pass C with the next pass A).
-        algo_flop_per_launch = 27.0 / PHASE_LAUNCHES * pairs * FLOP_PER_PAIR_PASS
-        achieved = algo_flop_per_launch / (phase_us * 1e-6) / 1e12 if phase_us == phase_us and phase_us > 0 else None
+        # `lanes` launches (one per half batch, on two streams) run at the same time: the rate of the chip is the
+        # work of all of them over the duration of one
+        algo_flop_per_launch = 27.0 / PHASE_LAUNCHES * (pairs / lanes) * FLOP_PER_PAIR_PASS
+        achieved = lanes * algo_flop_per_launch / (phase_us * 1e-6) / 1e12 if phase_us == phase_us and phase_us > 0 else None
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
         if os.path.exists(pmc):
@@ -278,6 +282,7 @@ def main() -> None:
             'traffic': traffic,
             'avg_launch_us': phase_us,
             'launches_timed': phase_cnt,
+            'concurrent_launches': lanes,
             'algorithmic_flop_per_launch': algo_flop_per_launch,
         }
         ch_us = br['nndistance'] + br['nndistancegrad']

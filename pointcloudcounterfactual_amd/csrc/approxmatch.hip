@@ -30,6 +30,9 @@
 // (one read of match each).
 #include "pcc_common.hpp"
 
+#include <algorithm>
+#include <mutex>
+
 namespace {
 
 using pcc::sq3;
@@ -759,6 +762,9 @@ struct SortArgs {  // one entry per cloud; blockIdx.y selects it
     float *box[2];
     float *box64[2];
     int nb64[2];
+    // zero-fill riding along (replaces two memset launches): the two workgroups of a sample clear one region each
+    float *zero[2];
+    long long zero_stride[2], zero_count[2];  // per-sample stride and length in floats (multiples of 4)
 };
 
 // Bitonic sort of NPAD = kSortT*SLOTS 32-bit keys held in registers (element i = tid + kSortT*slot) by a
@@ -813,6 +819,11 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     const int which = blockIdx.y;
     const int n = a.n[which], n4 = a.n4[which], nb = a.nb[which], npad = a.npad[which];
     const int smp = blockIdx.x, tid = threadIdx.x, T = kSortT;
+    if (a.zero[which]) {  // fire-and-forget stores, hidden under the sort
+        float4 *z = reinterpret_cast<float4 *>(a.zero[which] + (size_t)smp * a.zero_stride[which]);
+        const long long cnt4 = a.zero_count[which] / 4;
+        for (long long i = tid; i < cnt4; i += T) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const float *p = a.xyz[which] + (size_t)smp * n * 3;
     float *so = a.soa[which] + (size_t)smp * 3 * n4;
     int *rk = a.rank[which] + (size_t)smp * n;
@@ -1633,20 +1644,43 @@ __global__ __launch_bounds__(256) void am_pair_kernel(PairArgs a) {
     }
 }
 
-// out[b][i][:] = scale[b] * sum_t part[b][t][rank[b][i]][:] -- second stage of the implicit-match gradients: adds the
-// partials in index order and carries the result from the sorted index space back to the caller's point order.
-__global__ __launch_bounds__(256) void reduce_unsort_kernel(int parts, int npts, int pitch, const float *__restrict__ part,
-                                                             const int *__restrict__ rank, const float *__restrict__ scale,
-                                                             float *__restrict__ out) {
-    const int smp = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+// Second stage of the implicit path: partials are added in index order (deterministic) and the gradients carried from
+// the sorted index space back to the caller's point order through `rank`.
+// The three second-stage reductions of the implicit path in ONE launch (blockIdx.z: 0 = grad1, 1 = grad2, 2 = cost).
+struct FinishArgs {
+    int parts[3], npts[2], pitch[2];
+    const float *part[3];
+    const int *rank[2];
+    const float *scale;
+    float *out[3];
+};
+__global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
+    __shared__ float red[256];
+    const int which = blockIdx.z, smp = blockIdx.y, tid = threadIdx.x;
+    if (which == 2) {  // cost[b] = sum of the workgroup partials, fixed order
+        if (blockIdx.x) return;
+        const int parts = f.parts[2];
+        float s = 0.f;
+        for (int i = tid; i < parts; i += 256) s += f.part[2][(size_t)smp * parts + i];
+        red[tid] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) red[tid] += red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) f.out[2][smp] = red[0];
+        return;
+    }
+    if (!f.out[which]) return;
+    const int npts = f.npts[which], pitch = f.pitch[which], parts = f.parts[which];
+    const int i = blockIdx.x * 256 + tid;
     if (i >= npts * 3) return;
     const int pt = i / 3, c = i - pt * 3;
-    const int s = rank[(size_t)smp * npts + pt];
-    const float *p = part + ((size_t)smp * parts * pitch + s) * 3 + c;
+    const int s = f.rank[which][(size_t)smp * npts + pt];
+    const float *p = f.part[which] + ((size_t)smp * parts * pitch + s) * 3 + c;
     float acc = p[0];
     for (int t = 1; t < parts; t++) acc += p[(size_t)t * pitch * 3];
-    out[(size_t)smp * npts * 3 + i] = scale ? acc * scale[smp] : acc;
+    f.out[which][(size_t)smp * npts * 3 + i] = f.scale ? acc * f.scale[smp] : acc;
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -1805,8 +1839,14 @@ struct WsLayout {
 };
 
 int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const float *xyz2, float *soa1, float *soa2,
-                int *rank1, int *rank2, float *box1, float *box2, float *box64_1, float *box64_2, hipStream_t st) {
+                int *rank1, int *rank2, float *box1, float *box2, float *box64_1, float *box64_2, float *rem, float *lv,
+                hipStream_t st) {
     SortArgs a{};
+    // the padded tails of the weight rows are staged as float4: they must be finite (their candidates sit at the
+    // origin with these weights), and V_COWN relies on zero-filled level arrays for the exhausted owners it never
+    // touches: remain rows are cleared by the workgroup sorting set1, level rows by the one sorting set2
+    a.zero[0] = rem; a.zero_stride[0] = a.zero_count[0] = (long long)L.n4 + 2LL * L.m4;
+    a.zero[1] = lv; a.zero_stride[1] = a.zero_count[1] = (long long)kLevels * ((long long)L.n4 + L.m4);
     const int nn[2] = {n, m};
     int slots = 4;
     for (int w = 0; w < 2; w++) {
@@ -1835,35 +1875,55 @@ int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const
     return pcc::check_launch("approxmatch(sort)");
 }
 
+// One internal side stream per device: the second half of a large batch runs its 19 dependent phase launches there
+// while the first half runs on the caller's stream, so that one half's kernels fill the launch / drain bubbles of
+// the other's (each launch is a chain link of ~20 us with 4-8 us of fixed cost).  Fork and join are events on the
+// caller's stream: for the caller the call still is "enqueue on `stream`, no host synchronisation".
+hipStream_t side_stream() {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
+        streams[dev] = nullptr;
+        (void)hipGetLastError();
+    }
+    return streams[dev];
+}
+
+struct ForkJoin {  // side waits for everything enqueued on main so far; at scope exit main waits for side
+    hipStream_t main, side;
+    bool ok = false;
+    ForkJoin(hipStream_t m, hipStream_t s) : main(m), side(s) {
+        hipEvent_t ev;
+        if (!side || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
+        ok = hipEventRecord(ev, main) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
+        (void)hipEventDestroy(ev);  // released once the recorded work has completed
+    }
+    ~ForkJoin() {
+        if (!ok) return;
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipStreamSynchronize(side);  // cannot order the streams any other way
+            return;
+        }
+        (void)hipEventRecord(ev, side);
+        (void)hipStreamWaitEvent(main, ev, 0);
+        (void)hipEventDestroy(ev);
+    }
+};
+
 // Sort + the 19 passes: leaves the nine (ratioL | ratioR) level rows and remainL | remainR in the workspace, in the
 // Hilbert-sorted index space.
 int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const WsLayout &L, char *base, hipStream_t st,
                bool *persist_out) {
-    float *soa1 = reinterpret_cast<float *>(base + L.soa1), *soa2 = reinterpret_cast<float *>(base + L.soa2);
-    int *rank1 = reinterpret_cast<int *>(base + L.rank1), *rank2 = reinterpret_cast<int *>(base + L.rank2);
-    float *box1 = reinterpret_cast<float *>(base + L.box1), *box2 = reinterpret_cast<float *>(base + L.box2);
-    float *box64_1 = reinterpret_cast<float *>(base + L.box64_1), *box64_2 = reinterpret_cast<float *>(base + L.box64_2);
-    float *rem = reinterpret_cast<float *>(base + L.rem);
-    float *lv = reinterpret_cast<float *>(base + L.lv);
     const LevelConsts lc = make_levels();
     float multiL, multiR;  // approxmatch.cu:6-12 (integer division)
     if (n >= m) { multiL = 1; multiR = (float)(n / m); }
     else { multiL = (float)(m / n); multiR = 1; }
     const long long nm4 = (long long)L.n4 + L.m4;  // sorted-space level row: ratioL (n4) | ratioR (m4)
     const long long rs = (long long)L.n4 + 2LL * L.m4;  // remain row: remainL (n4) | remainR ping (m4) | pong (m4)
-
-    int rc = sort_clouds(b, L, n, m, xyz1, xyz2, soa1, soa2, rank1, rank2, box1, box2, box64_1, box64_2, st);
-    if (rc) return rc;
-    // the padded tails of the weight rows are staged as float4: they must be finite (their candidates sit at
-    // the origin with these weights); zero them once
-    // ... and V_COWN relies on zero-filled level arrays for the exhausted owners it never touches
-    {
-        hipError_t e = hipMemsetAsync(rem, 0, (size_t)b * (rs + kLevels * nm4) * sizeof(float), st);
-        if (e != hipSuccess) {
-            pcc::set_error((int)e, "approxmatch: memset failed");
-            return (int)e;
-        }
-    }
 
     static const float cut_scale = [] {  // debugging aid: PCC_AM_CUTSCALE < 1 skips more than is exact
         const char *e = std::getenv("PCC_AM_CUTSCALE");
@@ -1880,14 +1940,6 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         const char *e = std::getenv("PCC_AM_DEBUG");
         return (e && e[0] == '1') ? 1 : 0;
     }();
-    Sched sc{};
-    sc.n = n; sc.m = m; sc.n4 = L.n4; sc.m4 = L.m4; sc.nb1 = L.nb1; sc.nb2 = L.nb2; sc.nb64_1 = L.nb64_1; sc.nb64_2 = L.nb64_2;
-    sc.soa1 = soa1; sc.soa2 = soa2; sc.box1 = box1; sc.box2 = box2; sc.box64_1 = box64_1; sc.box64_2 = box64_2;
-    sc.rem = rem; sc.lv = lv; sc.multiL = multiL; sc.multiR = multiR; sc.cut_scale = cut_scale;
-    sc.skip = cull_enabled() ? 1 : 0;
-    sc.lc = lc;
-    sc.dbg = dbg_counters;
-    sc.dbg_counts = dbg_counts;
 
     // Persistent schedule (one launch for the 19 passes) when the whole batch group can be co-resident and fills the
     // chip; otherwise one launch per pass.
@@ -1922,11 +1974,66 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         const char *e = std::getenv("PCC_AM_NOCLIST");
         return !(e && e[0] == '1');
     }();
-    if (!use_persist && clist_enabled) {
-        sc.clist = reinterpret_cast<float *>(base + L.clist);
-        sc.clist_cnt = reinterpret_cast<int *>(base + L.clist_cnt);
+    static const bool split_enabled = [] {  // PCC_AM_NOSPLIT=1: everything on the caller's stream (A/B measurements)
+        const char *e = std::getenv("PCC_AM_NOSPLIT");
+        return !(e && e[0] == '1');
+    }();
+
+    // Lanes: disjoint sample ranges that run the same schedule on different streams.  Two lanes when each half still
+    // is a sizeable launch (B=32, N=2048: EMD forward+backward 530 -> 49x us); every workspace section is indexed
+    // [sample][...], so a lane is the same schedule on pointers offset to its first sample.
+    struct Lane {
+        int s0, bc;
+        hipStream_t st;
+        Sched sc;
+    };
+    Lane lanes[2];
+    int nlanes = 1;
+    hipStream_t side = nullptr;
+    if (!use_persist && split_enabled && !dbg_counters && b >= 8 && (long long)b * std::max(n, m) >= 32768) side = side_stream();
+    ForkJoin fj(st, side);
+    if (fj.ok) nlanes = 2;
+    for (int l = 0; l < nlanes; l++) {
+        Lane &ln = lanes[l];
+        ln.s0 = l == 0 ? 0 : b / 2;
+        ln.bc = nlanes == 1 ? b : (l == 0 ? b / 2 : b - b / 2);
+        ln.st = l == 0 ? st : side;
+        const size_t s0 = (size_t)ln.s0;
+        Sched &sc = ln.sc;
+        sc = Sched{};
+        sc.n = n; sc.m = m; sc.n4 = L.n4; sc.m4 = L.m4; sc.nb1 = L.nb1; sc.nb2 = L.nb2; sc.nb64_1 = L.nb64_1; sc.nb64_2 = L.nb64_2;
+        sc.soa1 = reinterpret_cast<float *>(base + L.soa1) + s0 * 3 * L.n4;
+        sc.soa2 = reinterpret_cast<float *>(base + L.soa2) + s0 * 3 * L.m4;
+        sc.box1 = reinterpret_cast<float *>(base + L.box1) + s0 * L.nb1 * 8;
+        sc.box2 = reinterpret_cast<float *>(base + L.box2) + s0 * L.nb2 * 8;
+        sc.box64_1 = reinterpret_cast<float *>(base + L.box64_1) + s0 * L.nb64_1 * 8;
+        sc.box64_2 = reinterpret_cast<float *>(base + L.box64_2) + s0 * L.nb64_2 * 8;
+        sc.rem = reinterpret_cast<float *>(base + L.rem) + s0 * rs;
+        sc.lv = reinterpret_cast<float *>(base + L.lv) + s0 * kLevels * nm4;
+        sc.multiL = multiL; sc.multiR = multiR; sc.cut_scale = cut_scale;
+        sc.skip = cull_enabled() ? 1 : 0;
+        sc.lc = lc;
+        sc.dbg = l == 0 ? dbg_counters : nullptr;
+        sc.dbg_counts = dbg_counts;
+        if (!use_persist && clist_enabled) {
+            sc.clist = reinterpret_cast<float *>(base + L.clist) + s0 * 5 * L.m4;
+            sc.clist_cnt = reinterpret_cast<int *>(base + L.clist_cnt) + s0;
+        }
     }
+    int rc = PCC_OK;
+    for (int l = 0; l < nlanes && !rc; l++) {
+        const Lane &ln = lanes[l];
+        const size_t s0 = (size_t)ln.s0;
+        rc = sort_clouds(ln.bc, L, n, m, xyz1 + s0 * n * 3, xyz2 + s0 * m * 3, const_cast<float *>(ln.sc.soa1),
+                         const_cast<float *>(ln.sc.soa2), reinterpret_cast<int *>(base + L.rank1) + s0 * n,
+                         reinterpret_cast<int *>(base + L.rank2) + s0 * m, const_cast<float *>(ln.sc.box1),
+                         const_cast<float *>(ln.sc.box2), const_cast<float *>(ln.sc.box64_1),
+                         const_cast<float *>(ln.sc.box64_2), ln.sc.rem, ln.sc.lv, ln.st);
+    }
+    if (rc) return rc;
+
     if (use_persist) {
+        const Sched &sc = lanes[0].sc;
         unsigned *counters = reinterpret_cast<unsigned *>(base + L.sync);
         if (hipMemsetAsync(counters, 0, ((size_t)b + 1) * sizeof(unsigned), st) != hipSuccess)
             return pcc::invalid("approxmatch: memset failed");
@@ -1939,18 +2046,23 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         rc = pcc::check_launch("approxmatch(persistent)");
         if (rc) return rc;
     } else {
-        pcc::ProfScope seq("am_phase_sequence", st, true);
-        for (int p = 0; p < sched_phases(); p++) {
-            int mode, var;
-            const PhaseArgs a = build_phase(sc, p, &mode, &var);
-            switch (mode) {
-            case PH_A: rc = launch_phase<PH_A>(a, b, var, st, "approxmatch(A)"); break;
-            case PH_B: rc = launch_phase<PH_B>(a, b, var, st, "approxmatch(B)"); break;
-            case PH_CA: rc = launch_phase<PH_CA>(a, b, var, st, "approxmatch(CA)"); break;
-            default: rc = launch_phase<PH_C>(a, b, var, st, "approxmatch(C)"); break;
+        // pass p of every lane is enqueued before pass p+1 of any: the streams advance together
+        pcc::ProfScope seq0("am_phase_sequence", lanes[0].st, true);
+        pcc::ProfScope seq1("am_phase_sequence", lanes[nlanes - 1].st, true, nlanes == 2);
+        for (int p = 0; p < sched_phases() && !rc; p++) {
+            for (int l = 0; l < nlanes && !rc; l++) {
+                const Lane &ln = lanes[l];
+                int mode, var;
+                const PhaseArgs a = build_phase(ln.sc, p, &mode, &var);
+                switch (mode) {
+                case PH_A: rc = launch_phase<PH_A>(a, ln.bc, var, ln.st, "approxmatch(A)"); break;
+                case PH_B: rc = launch_phase<PH_B>(a, ln.bc, var, ln.st, "approxmatch(B)"); break;
+                case PH_CA: rc = launch_phase<PH_CA>(a, ln.bc, var, ln.st, "approxmatch(CA)"); break;
+                default: rc = launch_phase<PH_C>(a, ln.bc, var, ln.st, "approxmatch(C)"); break;
+                }
             }
-            if (rc) return rc;
         }
+        if (rc) return rc;
     }
     if (dbg_counters) {
         static int h[kDbgInts];
@@ -2061,13 +2173,18 @@ int match_cost_implicit_impl(int b, int n, int m, const float *xyz1, const float
     const dim3 grid(col_blocks, row_tiles, b);
     rc = q_cols == 2 ? launch_pair<2>(pa, grid, grad, st) : launch_pair<4>(pa, grid, grad, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(b), dim3(256), 0, st, col_blocks * row_tiles, pa.cost_part, cost);
-    if (grad) {
-        const int *rank1 = reinterpret_cast<const int *>(base + L.rank1), *rank2 = reinterpret_cast<const int *>(base + L.rank2);
-        hipLaunchKernelGGL(reduce_unsort_kernel, dim3(pcc::ceil_div(n * 3, 256), b), dim3(256), 0, st, row_tiles, n, L.n4,
-                           pa.part1, rank1, grad_cost, grad1);
-        hipLaunchKernelGGL(reduce_unsort_kernel, dim3(pcc::ceil_div(m * 3, 256), b), dim3(256), 0, st, col_blocks, m, L.m4,
-                           pa.part2, rank2, grad_cost, grad2);
+    FinishArgs f{};
+    f.parts[0] = row_tiles; f.parts[1] = col_blocks; f.parts[2] = col_blocks * row_tiles;
+    f.npts[0] = n; f.npts[1] = m; f.pitch[0] = L.n4; f.pitch[1] = L.m4;
+    f.part[0] = pa.part1; f.part[1] = pa.part2; f.part[2] = pa.cost_part;
+    f.rank[0] = reinterpret_cast<const int *>(base + L.rank1);
+    f.rank[1] = reinterpret_cast<const int *>(base + L.rank2);
+    f.scale = grad_cost;
+    f.out[0] = grad ? grad1 : nullptr; f.out[1] = grad ? grad2 : nullptr; f.out[2] = cost;
+    {
+        pcc::ProfScope prof("pair_finish_kernel", st);
+        const int blocks = grad ? pcc::ceil_div(std::max(n, m) * 3, 256) : 1;
+        hipLaunchKernelGGL(pair_finish_kernel, dim3(blocks, b, 3), dim3(256), 0, st, f);
     }
     return pcc::check_launch("match_cost(reduce)");
 }

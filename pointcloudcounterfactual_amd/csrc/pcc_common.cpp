@@ -39,8 +39,8 @@ void prof_clear() {
 }  // namespace
 
 bool profiling() { return g_prof_mode != 0; }
-ProfScope::ProfScope(const char *kernel, hipStream_t s, bool coarse) : st(s), name(kernel) {
-    if (g_prof_mode != (coarse ? 2 : 1)) return;
+ProfScope::ProfScope(const char *kernel, hipStream_t s, bool coarse, bool enabled) : st(s), name(kernel) {
+    if (!enabled || g_prof_mode != (coarse ? 2 : 1)) return;
     if (hipEventCreate(&start) != hipSuccess) {
         start = nullptr;
         return;

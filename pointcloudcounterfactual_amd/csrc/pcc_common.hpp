@@ -45,7 +45,7 @@ struct ProfScope {
     hipStream_t st;
     const char *name;
     // coarse scopes bracket a whole launch sequence and are recorded only in mode 2 (no per-launch events inside)
-    ProfScope(const char *kernel, hipStream_t s, bool coarse = false);
+    ProfScope(const char *kernel, hipStream_t s, bool coarse = false, bool enabled = true);
     ~ProfScope();
 };
 
