@@ -371,6 +371,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     if (tid < TQ && tid < n_valid) own_e = COWN ? own_idx[tid] : tile * TQ + tid;
 
     float ox[R], oy[R], oz[R], s0[R], s1[R];
+    float t0x = 0.f, t1x = 0.f;  // second accumulators of the R == 1 shapes
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int e = r * 64 + lane;
@@ -557,21 +558,40 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
                     const float d1 = sq3(x.y - ox[r], y.y - oy[r], z.y - oz[r]);
                     const float d2 = sq3(x.z - ox[r], y.z - oy[r], z.z - oz[r]);
                     const float d3 = sq3(x.w - ox[r], y.w - oy[r], z.w - oz[r]);
-                    s0[r] = __builtin_fmaf(fast_exp2(c0 * d0), wa.x, s0[r]);
-                    s0[r] = __builtin_fmaf(fast_exp2(c0 * d1), wa.y, s0[r]);
-                    s0[r] = __builtin_fmaf(fast_exp2(c0 * d2), wa.z, s0[r]);
-                    s0[r] = __builtin_fmaf(fast_exp2(c0 * d3), wa.w, s0[r]);
-                    if (NW == 2) {
-                        s1[r] = __builtin_fmaf(fast_exp2(c1 * d0), wb.x, s1[r]);
-                        s1[r] = __builtin_fmaf(fast_exp2(c1 * d1), wb.y, s1[r]);
-                        s1[r] = __builtin_fmaf(fast_exp2(c1 * d2), wb.z, s1[r]);
-                        s1[r] = __builtin_fmaf(fast_exp2(c1 * d3), wb.w, s1[r]);
+                    if (R == 1) {
+                        // one owner per lane: a lone wave per SIMD would stall on a single dependent fma chain, so
+                        // even and odd candidates go to two accumulators (added once, after the loop)
+                        s0[r] = __builtin_fmaf(fast_exp2(c0 * d0), wa.x, s0[r]);
+                        t0x = __builtin_fmaf(fast_exp2(c0 * d1), wa.y, t0x);
+                        s0[r] = __builtin_fmaf(fast_exp2(c0 * d2), wa.z, s0[r]);
+                        t0x = __builtin_fmaf(fast_exp2(c0 * d3), wa.w, t0x);
+                        if (NW == 2) {
+                            s1[r] = __builtin_fmaf(fast_exp2(c1 * d0), wb.x, s1[r]);
+                            t1x = __builtin_fmaf(fast_exp2(c1 * d1), wb.y, t1x);
+                            s1[r] = __builtin_fmaf(fast_exp2(c1 * d2), wb.z, s1[r]);
+                            t1x = __builtin_fmaf(fast_exp2(c1 * d3), wb.w, t1x);
+                        }
+                    } else {
+                        s0[r] = __builtin_fmaf(fast_exp2(c0 * d0), wa.x, s0[r]);
+                        s0[r] = __builtin_fmaf(fast_exp2(c0 * d1), wa.y, s0[r]);
+                        s0[r] = __builtin_fmaf(fast_exp2(c0 * d2), wa.z, s0[r]);
+                        s0[r] = __builtin_fmaf(fast_exp2(c0 * d3), wa.w, s0[r]);
+                        if (NW == 2) {
+                            s1[r] = __builtin_fmaf(fast_exp2(c1 * d0), wb.x, s1[r]);
+                            s1[r] = __builtin_fmaf(fast_exp2(c1 * d1), wb.y, s1[r]);
+                            s1[r] = __builtin_fmaf(fast_exp2(c1 * d2), wb.z, s1[r]);
+                            s1[r] = __builtin_fmaf(fast_exp2(c1 * d3), wb.w, s1[r]);
+                        }
                     }
                 }
             }
         }
     }
     PCC_ST(4);
+    if (R == 1) {
+        s0[0] += t0x;
+        s1[0] += t1x;
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         red[(0 * S + w) * TQ + r * 64 + lane] = s0[r];
@@ -772,7 +792,7 @@ struct SortArgs {  // one entry per cloud; blockIdx.y selects it
 // strides 64 and 128 go through LDS (18 cheap 4-wave barriers for 2048 keys).  Fully unrolled so that every
 // register index is static.  A key is (truncated Hilbert code << idx_bits) | point index: keys are unique and
 // one v_min_u32 / v_max_u32 pair is a whole compare-exchange.
-constexpr int kSortT = 256;
+constexpr int kSortT = 512;
 
 template <int SLOTS>
 __device__ __forceinline__ void bitonic_sort(unsigned (&key)[SLOTS], unsigned *lds, int tid) {
