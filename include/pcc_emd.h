@@ -3,9 +3,10 @@
  *
  * Replaces the reference's `emd_backend` pybind module (external/emd/src/emd.cpp:14-30 ->
  * emd_cuda_forward / emd_cuda_backward, external/emd/src/emd_cuda.cu:227-315).  The reference passes twelve
- * caller-allocated work tensors that its seven kernels per iteration communicate through; here one
- * persistent workgroup per sample keeps the auction state in LDS for all iterations, so only the inputs, the
- * two outputs and (for clouds too large for LDS) one scratch buffer cross the boundary.
+ * caller-allocated work tensors that its seven kernels per iteration communicate through; here a cluster of
+ * persistent workgroups per sample (one when the batch already fills the chip) runs all iterations with the target
+ * cloud and prices in LDS and workgroup / sample-local barriers instead of launches, so only the inputs and the two
+ * outputs cross the boundary (shared state and scratch come from the stream-ordered pool).
  *
  *   xyz1[b,n,3], xyz2[b,n,3] float32 in [0,1]^3 ; dist[b,n] float32 ; assignment[b,n] int32.
  * Deterministic where the reference races (GetMax / Assign, emd_cuda.cu:189,205): bidders of an iteration =

@@ -10,6 +10,9 @@
 #include "pcc_common.hpp"
 #include "pcc_emd.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 using pcc::sq3;
@@ -137,6 +140,170 @@ __global__ __launch_bounds__(1024) void auction_kernel(int n, const float *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Cluster schedule: C workgroups per sample instead of one (B=32 samples on one workgroup each use 32 of 256 CUs).
+// A workgroup owns a contiguous slice of the BIDDERS (set1 points) and keeps the whole target cloud plus a copy of
+// the prices in LDS; the state the workgroups of a sample share -- prices, assignment, inverse assignment, highest
+// increment and winner per target -- lives in global memory and is touched only with agent-scope (sc1) accesses /
+// atomics, so no cache-wide fence is needed (cdna_hip_programming.md Guideline 16).  Three sample-local barriers per
+// iteration replace the kernel boundaries of the reference (Bid | GetMax | Assign).  Same deterministic rules as the
+// one-workgroup kernel, hence the same bits: the best / second-best scan of a bidder does not depend on who runs
+// it, atomicMax / atomicMin are order-free, and every target has at most one winner per iteration.
+// All workgroups of a launch must be co-resident (the host sizes C and the launch for that); spins are bounded and
+// raise an error word that poisons the outputs instead of hanging.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float gldf(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gst(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gstf(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool cluster_barrier(unsigned *ctr, unsigned target, unsigned *err, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores / atomics have left the CU
+    __syncthreads();
+    __shared__ int failed;
+    if (tid == 0) {
+        failed = 0;
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 24) || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // a partner never arrived
+                failed = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return failed == 0;
+}
+
+__global__ __launch_bounds__(1024) void auction_cluster_kernel(int n, int C, const float *__restrict__ xyz1,
+                                                                const float *__restrict__ xyz2, float eps, int iters,
+                                                                float *__restrict__ dist, int *__restrict__ assignment,
+                                                                int *__restrict__ scratch, unsigned *__restrict__ sync,
+                                                                int smp0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, T = 1024;
+    const int smp = smp0 + (int)(blockIdx.x / C), c = (int)(blockIdx.x % C);
+    const int j0 = (int)((long long)n * c / C), j1 = (int)((long long)n * (c + 1) / C);
+    const int njmax = (n + C - 1) / C + 1;
+    float *sx = reinterpret_cast<float *>(smem);
+    float *sy = sx + n, *sz = sy + n, *pr = sz + n;       // targets + this iteration's prices
+    int *unass = reinterpret_cast<int *>(pr + n);          // [njmax] own unassigned bidders
+    int *bidl = unass + njmax;                             // [njmax] their targets   (indexed like unass)
+    float *incl = reinterpret_cast<float *>(bidl + njmax);  // [njmax] their increments
+    int *cnt = reinterpret_cast<int *>(incl + njmax);      // [4]
+
+    const float *p1 = xyz1 + (size_t)smp * n * 3, *p2 = xyz2 + (size_t)smp * n * 3;
+    int *ass = assignment + (size_t)smp * n;
+    int *sc = scratch + (size_t)smp * 4 * n;
+    float *price = reinterpret_cast<float *>(sc);
+    int *inv = sc + n, *max_inc = sc + 2 * n, *win = sc + 3 * n;
+    unsigned *err = sync;                                  // one error word, then the per-sample records:
+    unsigned *sy_ctr = sync + 1 + (size_t)smp * (2 + iters);  // [0] barrier counter, [1] unused, [2 + it] bidders of iteration it
+    unsigned barriers = 0;
+
+    for (int k = tid; k < n; k += T) {
+        sx[k] = p2[k * 3 + 0];
+        sy[k] = p2[k * 3 + 1];
+        sz[k] = p2[k * 3 + 2];
+    }
+    for (int k = j0 + tid; k < j1; k += T) {  // this workgroup initialises its share of the shared state
+        gstf(&price[k], 0.f);
+        gst(&inv[k], -1);
+        gst(&max_inc[k], 0);  // emd_module.py:41 zeros
+        gst(&ass[k], -1);
+    }
+    bool ok = cluster_barrier(sy_ctr, (unsigned)C * ++barriers, err, tid);
+
+    for (int it = 0; ok && it < iters; it++) {
+        const bool last = it == iters - 1;
+        if (tid == 0) cnt[0] = 0;
+        for (int k = tid; k < n; k += T) pr[k] = gldf(&price[k]);
+        __syncthreads();
+        for (int j = j0 + tid; j < j1; j += T)
+            if (gld(&ass[j]) == -1) unass[atomicAdd(&cnt[0], 1)] = j;  // order irrelevant to the result
+        __syncthreads();
+        const int nu = cnt[0];
+        if (tid == 0 && nu) __hip_atomic_fetch_add(&sy_ctr[2 + it], (unsigned)nu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- Bid (emd_cuda.cu:94-178): TPB lanes share one bidder and split the targets ----
+        int tpb = 1;
+        while (tpb < 64 && tpb * 2 * nu <= T) tpb *= 2;
+        const int per_round = T / tpb;
+        const int sub = tid & (tpb - 1);
+        for (int u0 = 0; u0 < nu; u0 += per_round) {
+            const int u = u0 + tid / tpb;
+            const bool live = u < nu;
+            const int j = live ? unass[u] : unass[0];
+            const float x1 = p1[j * 3 + 0], y1 = p1[j * 3 + 1], z1 = p1[j * 3 + 2];
+            Cand cd{-1e9f, -1e9f, -1};
+            for (int k = sub; k < n; k += tpb) {
+                const float s = __builtin_sqrtf(sq3(sx[k] - x1, sy[k] - y1, sz[k] - z1));
+                const float d = (float)(3.0 - (double)s - (double)pr[k]);
+                if (d > cd.best) {
+                    cd.better = cd.best;
+                    cd.best = d;
+                    cd.best_i = k;
+                } else if (d > cd.better) {
+                    cd.better = d;
+                }
+            }
+            for (int off = 1; off < tpb; off <<= 1) {
+                Cand o;
+                o.best = __shfl_xor(cd.best, off, 64);
+                o.better = __shfl_xor(cd.better, off, 64);
+                o.best_i = __shfl_xor(cd.best_i, off, 64);
+                cd = merge(cd, o);
+            }
+            if (live && sub == 0) {
+                const float bi = cd.best - cd.better + eps;  // :174
+                bidl[u] = cd.best_i;
+                incl[u] = bi;
+                // :175 (bi > 0: int order == float order)
+                __hip_atomic_fetch_max(&max_inc[cd.best_i], __float_as_int(bi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gst(&win[cd.best_i], 0x7fffffff);
+            }
+        }
+        ok = cluster_barrier(sy_ctr, (unsigned)C * ++barriers, err, tid);
+        if (!ok) break;
+        // everything assigned: the remaining iterations (and the forced one) are no-ops; every workgroup of the
+        // sample reads the same total, so the exit is uniform
+        if (__hip_atomic_load(&sy_ctr[2 + it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;
+        // ---- GetMax (:180-193): lowest qualifying bidder wins ----
+        for (int u = tid; u < nu; u += T) {
+            const int j = unass[u], t = bidl[u];
+            const double bi = incl[u], mi = __int_as_float(gld(&max_inc[t]));
+            if (bi - 1e-6 <= mi && mi <= bi + 1e-6) __hip_atomic_fetch_min(&win[t], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ok = cluster_barrier(sy_ctr, (unsigned)C * ++barriers, err, tid);
+        if (!ok) break;
+        // ---- Assign (:195-214) ----
+        for (int u = tid; u < nu; u += T) {
+            const int j = unass[u], t = bidl[u];
+            if (last || gld(&win[t]) == j) {
+                const int owner = gld(&inv[t]);
+                if (!last && owner != -1) gst(&ass[owner], -1);
+                gst(&inv[t], j);
+                gst(&ass[j], t);
+                if (last) __hip_atomic_fetch_add(&price[t], incl[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else gstf(&price[t], pr[t] + incl[u]);  // the only writer of price[t] in this iteration
+                gst(&max_inc[t], __float_as_int(-1e9f));
+            }
+        }
+        ok = cluster_barrier(sy_ctr, (unsigned)C * ++barriers, err, tid);
+    }
+    __syncthreads();
+    const bool bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    for (int j = j0 + tid; j < j1; j += T) {  // CalcDist :216-225
+        const int k = gld(&ass[j]);
+        const bool valid = !bad && k >= 0 && k < n;
+        const int kk = valid ? k : 0;
+        const float d = sq3(p1[j * 3 + 0] - sx[kk], p1[j * 3 + 1] - sy[kk], p1[j * 3 + 2] - sz[kk]);
+        dist[(size_t)smp * n + j] = valid ? d : __builtin_nanf("");
+    }
+}
+
 __global__ __launch_bounds__(256) void auction_bwd_kernel(size_t total, int n, const float *__restrict__ xyz1,
                                                            const float *__restrict__ xyz2,
                                                            const float *__restrict__ grad_dist,
@@ -162,6 +329,55 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
     if (b == 0) return PCC_OK;
     if (!xyz1 || !xyz2 || !dist || !assignment) return pcc::invalid("auction: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // ---- cluster schedule: C workgroups per sample when they can all be resident at once ----
+    {
+        static const int cl_override = [] {  // PCC_AUCTION_CLUSTER=1 forces one workgroup per sample, 2..16 forces C
+            const char *e = std::getenv("PCC_AUCTION_CLUSTER");
+            return e ? std::atoi(e) : 0;
+        }();
+        static const int cus = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+            return v;
+        }();
+        int C = 1;
+        if (cl_override != 1 && n >= 512 && cus > 0) {
+            C = cl_override > 1 ? cl_override : 8;
+            while (C > 1 && (n / C < 128)) C /= 2;          // a slice of at least 128 bidders
+            while (C > 1 && C > cus) C /= 2;                 // one workgroup per CU: residency by construction
+        }
+        const int njmax = (n + C - 1) / C + 1;
+        const size_t lds = (size_t)4 * n * 4 + (size_t)3 * njmax * 4 + 16;
+        if (C > 1 && lds <= 160 * 1024 - 256) {
+            static bool attr2 = [] {  // the kernel also has a few bytes of static LDS (barrier flag)
+                const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(auction_cluster_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
+                if (!ok) (void)hipGetLastError();
+                return ok;
+            }();
+            (void)attr2;
+            const int group = std::max(1, cus / C);          // samples per launch
+            const size_t sync_words = 1 + (size_t)b * (2 + iters);
+            const size_t bytes = (size_t)b * 4 * n * 4 + sync_words * 4;
+            char *ws = nullptr;
+            if (hipMallocAsync(reinterpret_cast<void **>(&ws), bytes, st) != hipSuccess) {
+                (void)hipGetLastError();
+                pcc::set_error(PCC_ENOMEM, "auction: workspace hipMallocAsync failed");
+                return PCC_ENOMEM;
+            }
+            int *scratch = reinterpret_cast<int *>(ws);
+            unsigned *sync = reinterpret_cast<unsigned *>(ws + (size_t)b * 4 * n * 4);
+            (void)hipMemsetAsync(sync, 0, sync_words * 4, st);
+            for (int s0 = 0; s0 < b; s0 += group) {
+                const int gb = std::min(group, b - s0);
+                pcc::ProfScope prof("auction_cluster_kernel", st);
+                hipLaunchKernelGGL(auction_cluster_kernel, dim3((unsigned)(gb * C)), dim3(1024), lds, st, n, C, xyz1, xyz2, eps,
+                                   iters, dist, assignment, scratch, sync, s0);
+            }
+            (void)hipFreeAsync(ws, st);
+            return pcc::check_launch("auction_forward(cluster)");
+        }
+    }
     const size_t hot = (size_t)5 * n * 4 + 16, state = (size_t)5 * n * 4;
     const int in_lds = hot + state <= 160 * 1024;
     const size_t lds = in_lds ? hot + state : hot;
