@@ -2012,7 +2012,15 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
     Lane lanes[2];
     int nlanes = 1;
     hipStream_t side = nullptr;
-    if (!use_persist && split_enabled && !dbg_counters && b >= 8 && (long long)b * std::max(n, m) >= 32768) side = side_stream();
+    if (!use_persist && split_enabled && !dbg_counters && b >= 8 && (long long)b * std::max(n, m) >= 32768) {
+        // not while the caller's stream is being captured into a graph: the capture stays a single-stream chain
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+            (void)hipGetLastError();
+            cap = hipStreamCaptureStatusNone;
+        }
+        if (cap == hipStreamCaptureStatusNone) side = side_stream();
+    }
     ForkJoin fj(st, side);
     if (fj.ok) nlanes = 2;
     for (int l = 0; l < nlanes; l++) {
