@@ -425,3 +425,43 @@ def test_chamfer_fused_equals_nn_distance_expression(cuda, b, n, m, reduction):
     np.testing.assert_allclose(t2.grad.cpu().numpy(), u2.grad.cpu().numpy(), rtol=1e-5, atol=1e-7)
     with pytest.raises(ValueError):
         chamfer(t1, t2, 'max')
+
+
+def test_two_lane_schedule_equals_single_stream(cuda):
+    """At the bench size (B=32, N=2048) the level passes run as two half-batch lanes on two streams.
+    Per sample nothing changes, so the results carry the same bits as the single-stream schedule
+    (PCC_AM_NOSPLIT=1, read once per process: child process), run to run."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(91, 32, 2048, 2048)
+    t1, t2 = _dev(a, cuda), _dev(c, cuda)
+    r1 = backend.MatchCostImplicit(t1, t2, True)
+    r2 = backend.MatchCostImplicit(t1, t2, True)
+    assert all(torch.equal(x, y) for x, y in zip(r1, r2))
+    m1 = backend.ApproxMatchCost(t1, t2)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from tests.util import pair; from pointcloudcounterfactual_amd import backend\n"
+        "a, c = pair(91, 32, 2048, 2048)\n"
+        "t1, t2 = torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda()\n"
+        "cost, g1, g2 = backend.MatchCostImplicit(t1, t2, True)\n"
+        "m, t, mc = backend.ApproxMatchCost(t1, t2)\n"
+        "np.savez(sys.argv[1], cost=cost.cpu().numpy(), g1=g1.cpu().numpy(), g2=g2.cpu().numpy(), mc=mc.cpu().numpy(),\n"
+        "         temp=t.cpu().numpy(), rowmass=m.sum(2).cpu().numpy())\n"
+    ) % root
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, 'single.npz')
+        r = subprocess.run([sys.executable, '-c', code, f], env=dict(os.environ, PCC_AM_NOSPLIT='1'),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        z = np.load(f)
+    assert np.array_equal(r1[0].cpu().numpy(), z['cost'])
+    assert np.array_equal(r1[1].cpu().numpy(), z['g1']) and np.array_equal(r1[2].cpu().numpy(), z['g2'])
+    assert np.array_equal(m1[2].cpu().numpy(), z['mc']) and np.array_equal(m1[1].cpu().numpy(), z['temp'])
+    assert np.array_equal(m1[0].sum(2).cpu().numpy(), z['rowmass'])
