@@ -1901,17 +1901,18 @@ int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const
 // while the first half runs on the caller's stream, so that one half's kernels fill the launch / drain bubbles of
 // the other's (each launch is a chain link of ~20 us with 4-8 us of fixed cost).  Fork and join are events on the
 // caller's stream: for the caller the call still is "enqueue on `stream`, no host synchronisation".
-hipStream_t side_stream() {
+constexpr int kMaxLanes = 4;
+hipStream_t side_stream(int which) {  // which = 0 .. kMaxLanes - 2
     static std::mutex mu;
-    static hipStream_t streams[64] = {};
+    static hipStream_t streams[64][kMaxLanes - 1] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || which < 0 || which >= kMaxLanes - 1) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
-    if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) {
-        streams[dev] = nullptr;
+    if (!streams[dev][which] && hipStreamCreateWithFlags(&streams[dev][which], hipStreamNonBlocking) != hipSuccess) {
+        streams[dev][which] = nullptr;
         (void)hipGetLastError();
     }
-    return streams[dev];
+    return streams[dev][which];
 }
 
 struct ForkJoin {  // side waits for everything enqueued on main so far; at scope exit main waits for side
@@ -2009,8 +2010,13 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         hipStream_t st;
         Sched sc;
     };
-    Lane lanes[2];
+    Lane lanes[kMaxLanes];
     int nlanes = 1;
+    static const int want_lanes = [] {  // PCC_AM_LANES=2..4 (A/B measurements); default 2
+        const char *e = std::getenv("PCC_AM_LANES");
+        const int v = e ? std::atoi(e) : 2;
+        return v < 2 ? 2 : v > kMaxLanes ? kMaxLanes : v;
+    }();
     hipStream_t side = nullptr;
     if (!use_persist && split_enabled && !dbg_counters && b >= 8 && (long long)b * std::max(n, m) >= 32768) {
         // not while the caller's stream is being captured into a graph: the capture stays a single-stream chain
@@ -2019,15 +2025,17 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
             (void)hipGetLastError();
             cap = hipStreamCaptureStatusNone;
         }
-        if (cap == hipStreamCaptureStatusNone) side = side_stream();
+        if (cap == hipStreamCaptureStatusNone) side = side_stream(0);
     }
     ForkJoin fj(st, side);
-    if (fj.ok) nlanes = 2;
+    ForkJoin fj2(st, fj.ok && want_lanes >= 3 ? side_stream(1) : nullptr);
+    ForkJoin fj3(st, fj2.ok && want_lanes >= 4 ? side_stream(2) : nullptr);
+    if (fj.ok) nlanes = 2 + (fj2.ok ? 1 : 0) + (fj3.ok ? 1 : 0);
     for (int l = 0; l < nlanes; l++) {
         Lane &ln = lanes[l];
-        ln.s0 = l == 0 ? 0 : b / 2;
-        ln.bc = nlanes == 1 ? b : (l == 0 ? b / 2 : b - b / 2);
-        ln.st = l == 0 ? st : side;
+        ln.s0 = (int)((long long)b * l / nlanes);
+        ln.bc = (int)((long long)b * (l + 1) / nlanes) - ln.s0;
+        ln.st = l == 0 ? st : l == 1 ? fj.side : l == 2 ? fj2.side : fj3.side;
         const size_t s0 = (size_t)ln.s0;
         Sched &sc = ln.sc;
         sc = Sched{};
@@ -2078,7 +2086,9 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
     } else {
         // pass p of every lane is enqueued before pass p+1 of any: the streams advance together
         pcc::ProfScope seq0("am_phase_sequence", lanes[0].st, true);
-        pcc::ProfScope seq1("am_phase_sequence", lanes[nlanes - 1].st, true, nlanes == 2);
+        pcc::ProfScope seq1("am_phase_sequence", lanes[nlanes > 1 ? 1 : 0].st, true, nlanes >= 2);
+        pcc::ProfScope seq2("am_phase_sequence", lanes[nlanes > 2 ? 2 : 0].st, true, nlanes >= 3);
+        pcc::ProfScope seq3("am_phase_sequence", lanes[nlanes > 3 ? 3 : 0].st, true, nlanes >= 4);
         for (int p = 0; p < sched_phases() && !rc; p++) {
             for (int l = 0; l < nlanes && !rc; l++) {
                 const Lane &ln = lanes[l];
