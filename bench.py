@@ -48,6 +48,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the timings of the rows outside the headline metric')
     ap.add_argument('--cpu-clouds', type=int, default=0, help='clouds in the CPU-baseline sample (0 = auto)')
     ap.add_argument('--emd-mode', choices=['implicit', 'fused', 'reference'], default='implicit',
                     help="how match_cost carries out ApproxMatch -> MatchCost / MatchCostGrad (losses.MatchCostFunction.mode): "
@@ -134,6 +135,46 @@ def phase_kernel_time_us(recon_t, ref_t, steps: int) -> tuple[float, int, int]:
     L.pcc_profile_read(b'am_phase_sequence', ctypes.byref(us), ctypes.byref(cnt))
     L.pcc_profile_enable(0)
     return us.value / PHASE_LAUNCHES, cnt.value * PHASE_LAUNCHES, max(1, cnt.value // steps)
+
+
+def other_rows_us(dev: torch.device) -> dict[str, float]:
+    """Durations (us, HIP events) of the other SURVEY.md 8(a) rows at the same batch: auction EMD (A12-A13, eps 0.005,
+    50 iterations) and the encoder primitives (A14-A17) at the DGCNN layer shapes.  Informational: not part of `value`."""
+    from emd import emdModule
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    def ev(fn, iters=5, warm=2) -> float:
+        for _ in range(warm):
+            fn()
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / iters * 1e3
+
+    g = torch.Generator().manual_seed(SEED)
+    out: dict[str, float] = {}
+    a = torch.rand(B_PER_GPU, N_POINTS, 3, generator=g).to(dev).requires_grad_(True)
+    b = torch.rand(B_PER_GPU, N_POINTS, 3, generator=g).to(dev)
+
+    def auction():
+        a.grad = None
+        emdModule()(a, b, 0.005, 50)[0].sum().backward()
+
+    out['auction_emd_fwd_bwd_eps0.005_iters50'] = ev(auction, iters=3, warm=1)
+    for c, k in ((3, 25), (64, 25), (128, 25), (3, 4)):
+        x = torch.randn(B_PER_GPU, c, N_POINTS, generator=g).to(dev)
+        out[f'knn_c{c}_k{k}'] = ev(lambda: ops.hip_knn(x, k))
+    x = torch.randn(B_PER_GPU, 64, N_POINTS, generator=g).to(dev)
+    idx = ops.hip_knn(x, 25)
+    out['graph_features_c64_k25_fwd'] = ev(lambda: ops.get_graph_features(x, idx, 25))
+    out['graph_max_pooling_c64_k25_fwd'] = ev(lambda: ops.graph_max_pooling(x, idx, 25))
+    x2 = torch.randn(B_PER_GPU, 1024, N_POINTS, generator=g).to(dev)
+    out['global_max_pool_c1024'] = ev(lambda: ops.global_max_pool(x2))
+    return out
 
 
 def cpu_baseline(recon: np.ndarray, ref: np.ndarray, clouds: int) -> dict:
@@ -297,6 +338,11 @@ def main() -> None:
         result['breakdown_us'] = br
         result['emd_clouds_per_s'] = B_PER_GPU / (br['match_cost_implicit_fwd_bwd'] * 1e-6)
         result['emd_clouds_per_s_materialised'] = B_PER_GPU / ((br['approxmatch_cost'] + br['matchcostgrad']) * 1e-6)
+        if not args.no_extras:
+            try:
+                result['other_rows_us'] = other_rows_us(dev)
+            except Exception as e:  # informational only: never lose the headline line
+                result['other_rows_us'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             ncl = args.cpu_clouds or min(B_PER_GPU, max(2, os.cpu_count() or 2))
             result['cpu_baseline'] = cpu_baseline(recon, ref, ncl)
