@@ -10,6 +10,12 @@ from __future__ import annotations
 import ctypes
 import os
 
+# torch FIRST: libpcc_structural.so needs libamdhip64.so.7, and the process must end up with ONE HIP runtime.  With
+# torch imported before the library is loaded, the loader resolves that name to the runtime torch already brought in
+# (the copy bundled in torch/lib); loaded the other way round, the library pulls /opt/rocm's copy, torch then loads
+# its own, and launches through the first runtime on memory of the second fail with hipErrorNoDevice.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('PCC_LIB_OVERRIDE') or os.path.join(_HERE, 'lib', 'libpcc_structural.so')  # override: A/B builds only
 

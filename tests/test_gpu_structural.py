@@ -465,3 +465,26 @@ def test_two_lane_schedule_equals_single_stream(cuda):
     assert np.array_equal(r1[1].cpu().numpy(), z['g1']) and np.array_equal(r1[2].cpu().numpy(), z['g2'])
     assert np.array_equal(m1[2].cpu().numpy(), z['mc']) and np.array_equal(m1[1].cpu().numpy(), z['temp'])
     assert np.array_equal(m1[0].sum(2).cpu().numpy(), z['rowmass'])
+
+
+def test_package_import_before_torch(cuda):
+    """The library must share torch's HIP runtime whatever the import order (``_lib`` imports torch before it loads
+    the shared object): a fresh process that imports the package first, as ``__graft_entry__.build()`` followed by
+    ``smoke()`` does, runs the kernels."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import pointcloudcounterfactual_amd, structural_losses, emd, pykeops\n"
+        "import torch\n"
+        "from structural_losses import nn_distance\n"
+        "x = torch.rand(2, 64, 3, device='cuda')\n"
+        "d1, d2 = nn_distance(x, x)\n"
+        "assert float(d1.abs().max()) == 0.0\n"
+        "print('ok')\n"
+    ) % root
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
