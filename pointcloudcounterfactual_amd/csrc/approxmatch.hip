@@ -1587,13 +1587,12 @@ __global__ __launch_bounds__(256) void am_pair_kernel(PairArgs a) {
                         csum = __builtin_fmaf(f, d[q], csum);
                         // t = (p2 - p1) match / |p1 - p2|: grad2 (rows) accumulates +t (approxmatch.cu:240-246), grad1
                         // (columns) the negated vector (:281-284)
-                        const float tx = ex[q] * f, ty = ey[q] * f, tz = ez[q] * f;
-                        g1[q][0] -= tx;
-                        g1[q][1] -= ty;
-                        g1[q][2] -= tz;
-                        rx += tx;
-                        ry += ty;
-                        rz += tz;
+                        g1[q][0] = __builtin_fmaf(-ex[q], f, g1[q][0]);
+                        g1[q][1] = __builtin_fmaf(-ey[q], f, g1[q][1]);
+                        g1[q][2] = __builtin_fmaf(-ez[q], f, g1[q][2]);
+                        rx = __builtin_fmaf(ex[q], f, rx);
+                        ry = __builtin_fmaf(ey[q], f, ry);
+                        rz = __builtin_fmaf(ez[q], f, rz);
                     } else {
                         csum = __builtin_fmaf(acc[q], __builtin_amdgcn_sqrtf(d[q]), csum);
                     }
