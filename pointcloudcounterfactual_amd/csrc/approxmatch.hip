@@ -247,7 +247,8 @@ struct PhaseLds {
     static constexpr int kRed = NW * S * 64 * R;      // partial sums [NW][S][TQ]
     static constexpr int kOwn = 64 * R;               // live-owner tile (ints)
     static constexpr int kWave = S;                   // (ints)
-    static constexpr int floats = kC + kBB + kRed + kOwn + kWave + 4;
+    static constexpr int kItems = CH / kBox;          // surviving candidate blocks of V_CULL (ints)
+    static constexpr int floats = kC + kBB + kRed + kOwn + kWave + 4 + kItems;
 };
 
 template <int MODE, int R, int S, int CH, int VAR, bool PERSIST>
@@ -266,6 +267,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     float *red = lds_bb + L::kBB;                      // [NW][S][TQ]
     int *own_idx = reinterpret_cast<int *>(red + L::kRed);
     int *wave_cnt = own_idx + L::kOwn;
+    int *items = wave_cnt + L::kWave + 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -516,34 +518,51 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         }
         __syncthreads();
         PCC_ST(3);
-        // blocks are dealt round-robin to the S waves: a contiguous slice of the Hilbert order is one compact
-        // region, so contiguous slices would make culling all-or-nothing per wave and leave the workgroup
-        // waiting for its nearest slice
-        for (int blk = w; blk < nblk; blk += S) {
+        // V_CULL: the (owner group, candidate block) box tests are done once, one block per thread, and the blocks some
+        // owner group needs are compacted (in order) into a work list: nothing is tested inside the pair loop and
+        // the S waves take the SURVIVING blocks round-robin, i.e. evenly (dealing all blocks round-robin left the
+        // workgroup waiting 20-30 % of the loop for the wave that happened to keep the most).  Round-robin rather
+        // than contiguous slices: a contiguous slice of the Hilbert order is one compact region.
+        int nitems = nblk;
+        if (CULL) {
+            int base_cnt = 0;
+            for (int b0 = 0; b0 < nblk; b0 += T) {
+                const int blk = b0 + tid;
+                int mask = 0;
+                if (blk < nblk) {
+                    const float4 lo = BB4[2 * blk], hi = BB4[2 * blk + 1];
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const float dx = fmaxf(fmaxf(olx[r] - hi.x, lo.x - ohx[r]), 0.f);
+                        const float dy = fmaxf(fmaxf(oly[r] - hi.y, lo.y - ohy[r]), 0.f);
+                        const float dz = fmaxf(fmaxf(olz[r] - hi.z, lo.z - ohz[r]), 0.f);
+                        // every pair of (owner group r, candidate block) has |d|^2 >= lb: all exponentials are exactly 0
+                        const bool keep = !(dx * dx + dy * dy + dz * dz > cut2);
+                        mask |= keep ? (1 << r) : 0;
+                    }
+                    if (a.dbg) {
+                        atomicAdd(&a.dbg[0], R);
+                        atomicAdd(&a.dbg[1], R - __popc(mask));
+                    }
+                }
+                int round_total;
+                const int pos = compact_pos<S>(mask != 0, w, lane, wave_cnt, round_total);
+                if (mask) items[base_cnt + pos] = blk | (mask << 16);
+                base_cnt += round_total;
+            }
+            __syncthreads();
+            nitems = base_cnt;
+        }
+        for (int it = w; it < nitems; it += S) {
+            int blk = it;
             int live[R];  // wave-uniform: does owner group r need this candidate block at all?
 #pragma unroll
             for (int r = 0; r < R; r++) live[r] = 1;
             if (CULL) {
-                const float4 lo = BB4[2 * blk], hi = BB4[2 * blk + 1];
-                int any = 0;
+                const int item = __builtin_amdgcn_readfirstlane(items[it]);
+                blk = item & 0xffff;
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const float dx = fmaxf(fmaxf(olx[r] - hi.x, lo.x - ohx[r]), 0.f);
-                    const float dy = fmaxf(fmaxf(oly[r] - hi.y, lo.y - ohy[r]), 0.f);
-                    const float dz = fmaxf(fmaxf(olz[r] - hi.z, lo.z - ohz[r]), 0.f);
-                    // every pair of (owner group r, candidate block) has |d|^2 >= lb: all exponentials are exactly 0
-                    const bool keep = !(dx * dx + dy * dy + dz * dz > cut2);
-                    live[r] = __builtin_amdgcn_readfirstlane((int)keep);
-                    any |= live[r];
-                }
-                if (a.dbg && lane == 0) {
-                    atomicAdd(&a.dbg[0], R);
-                    int sk = 0;
-#pragma unroll
-                    for (int r = 0; r < R; r++) sk += 1 - live[r];
-                    atomicAdd(&a.dbg[1], sk);
-                }
-                if (!any) continue;
+                for (int r = 0; r < R; r++) live[r] = (item >> (16 + r)) & 1;
             }
             const int g_end = min(blk * 4 + 4, ngroups);
             for (int g = blk * 4; g < g_end; g++) {
