@@ -37,6 +37,7 @@ SEED = 1234 + 2  # seed = 1234 + config id
 # = 12 flop + 1 exp, counted as 13.
 FLOP_PER_PAIR_PASS = 13.0
 PHASE_LAUNCHES = 19        # am_phase_kernel launches per approxmatch (27 reference passes, 8 of them fused pairwise)
+PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # vector lanes x clock (an FMA lane-op = 2 of the 157.3 TFLOP/s)
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector peak == FP32 dense MFMA peak
 PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
 CHAMFER_ALGO_BYTES = 6_815_744  # fwd 2,621,440 + bwd 4,194,304 at B=32, N=M=2048
@@ -304,10 +305,20 @@ def main() -> None:
         algo_flop_per_launch = 27.0 / PHASE_LAUNCHES * (pairs / lanes) * FLOP_PER_PAIR_PASS
         achieved = lanes * algo_flop_per_launch / (phase_us * 1e-6) / 1e12 if phase_us == phase_us and phase_us > 0 else None
         traffic = None
+        executed = None
         pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get('am_phase_kernel', {}).get('hbm_bytes_per_launch')
+                fam = json.load(open(pmc)).get('am_phase_kernel', {})
+                traffic = fam.get('hbm_bytes_per_launch')
+                insts = fam.get('valu_insts_per_launch')
+                if insts and phase_us == phase_us and phase_us > 0:
+                    # what the kernel EXECUTES (committed PMC pass: wave-level VALU instructions per launch x 64 lanes),
+                    # over the live launch duration, against the vector lane rate 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+                    rate = lanes * insts * 64 / (phase_us * 1e-6)
+                    executed = {'valu_lane_ops_per_s': rate, 'peak_lane_ops_per_s': PEAK_LANE_OPS,
+                                'frac': rate / PEAK_LANE_OPS, 'valu_insts_per_launch': insts,
+                                'source': 'profiles/pmc_summary.json (SQ_INSTS_VALU)'}
             except Exception:
                 traffic = None
         result['roofline'] = {
@@ -324,6 +335,10 @@ def main() -> None:
             'avg_launch_us': phase_us,
             'launches_timed': phase_cnt,
             'concurrent_launches': lanes,
+            'note': 'achieved counts ALGORITHMIC flops: every pair of every reference pass, including the terms that are '
+                    'exactly zero in float32 and that the kernels skip (underflowing exponentials, exhausted points); '
+                    'frac can therefore exceed the utilisation of the vector units, which `executed` reports',
+            'executed': executed,
             'algorithmic_flop_per_launch': algo_flop_per_launch,
         }
         ch_us = br['nndistance'] + br['nndistancegrad']

@@ -65,20 +65,23 @@ if pmc:
     summary = {}
     for k, d in pmc.items():
         if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
-            fetch_kib = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE'])
-            write_kib = sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])
             key = re.sub(r'<.*', '', k)
-            summary.setdefault(key, {'fetch_kib_raw': 0.0, 'write_kib': 0.0, 'variants': 0})
-            summary[key]['fetch_kib_raw'] += fetch_kib
-            summary[key]['write_kib'] += write_kib
-            summary[key]['variants'] += 1
+            n = len(d['FETCH_SIZE'])  # dispatches of this instantiation: the family average is dispatch-weighted
+            e = summary.setdefault(key, {'fetch_kib_raw': 0.0, 'write_kib': 0.0, 'valu_insts': 0.0, 'dispatches': 0})
+            e['fetch_kib_raw'] += sum(d['FETCH_SIZE'])
+            e['write_kib'] += sum(d['WRITE_SIZE']) * n / max(len(d['WRITE_SIZE']), 1)
+            if d.get('SQ_INSTS_VALU'):
+                e['valu_insts'] += sum(d['SQ_INSTS_VALU']) * n / len(d['SQ_INSTS_VALU'])
+            e['dispatches'] += n
     for key, v in summary.items():
-        n = v.pop('variants')
+        n = v['dispatches']
         v['fetch_kib_raw'] /= n
         v['write_kib'] /= n
+        # wave-level VALU instructions per launch (SQ_INSTS_VALU, summed over the chip): x64 = lane operations
+        v['valu_insts_per_launch'] = v.pop('valu_insts') / n
         # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2 (upper bound for
         # narrow accesses); WRITE_SIZE is exact.  Units are KiB.
         v['hbm_bytes_per_launch'] = (2.0 * v['fetch_kib_raw'] + v['write_kib']) * 1024.0
-        v['source'] = f'profiles/{out_tag}_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+        v['source'] = f'profiles/{out_tag}_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes)'
     json.dump(summary, open(os.path.join(P, 'pmc_summary.json'), 'w'), indent=1)
     print('wrote profiles/pmc_summary.json')
