@@ -488,3 +488,38 @@ def test_package_import_before_torch(cuda):
     ) % root
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
+def test_random_shape_sweep(cuda, oracle_mod):
+    """Seeded sweep over awkward shapes (sizes that are not multiples of 4 / 16 / 64, very unequal clouds, batches that
+    do and do not split into lanes): Chamfer bit-exact vs the oracle; approximate EMD cost vs the float64 recurrence;
+    implicit path vs materialised path."""
+    from pointcloudcounterfactual_amd import backend
+
+    rng = np.random.default_rng(2026)
+    for trial in range(24):
+        b = int(rng.choice([1, 2, 3, 5, 9]))
+        n = int(rng.integers(1, 700))
+        m = int(rng.integers(1, 700))
+        if trial % 6 == 0:
+            n, m = int(rng.integers(2000, 2300)), int(rng.integers(1, 40))
+        kind = 'uniform' if trial % 2 else 'recon'
+        a, c = pair(5000 + trial, b, n, m, kind)
+        t1, t2 = _dev(a, cuda), _dev(c, cuda)
+        d1, i1, d2, i2 = backend.NNDistance(t1, t2)
+        od1, oi1, od2, oi2 = oracle_mod.nndistance(a, c)
+        assert np.array_equal(i1.cpu().numpy(), oi1) and np.array_equal(i2.cpu().numpy(), oi2), (b, n, m)
+        assert np.array_equal(d1.cpu().numpy(), od1) and np.array_equal(d2.cpu().numpy(), od2), (b, n, m)
+        match, _temp, cost = backend.ApproxMatchCost(t1, t2)
+        g1, g2 = backend.MatchCostGrad(t1, t2, match)
+        cost_i, h1, h2 = backend.MatchCostImplicit(t1, t2, True)
+        om64, _ = oracle_mod.approxmatch_f64(a, c)
+        om32, _ = oracle_mod.approxmatch(a, c)
+        oc64 = oracle_mod.matchcost_f64(a, c, om64)
+        oc32 = oracle_mod.matchcost(a, c, om32)
+        tol = max(1e-5, 4 * np.abs(oc32 - oc64).max() / max(np.abs(oc64).max(), 1e-30))
+        np.testing.assert_allclose(cost.cpu().numpy(), oc64, rtol=tol, atol=1e-6, err_msg=str((b, n, m, kind)))
+        np.testing.assert_allclose(cost_i.cpu().numpy(), cost.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=str((b, n, m, kind)))
+        scale = max(float(g1.abs().max()), float(g2.abs().max()), 1e-30)
+        np.testing.assert_allclose(h1.cpu().numpy(), g1.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale, err_msg=str((b, n, m)))
+        np.testing.assert_allclose(h2.cpu().numpy(), g2.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale, err_msg=str((b, n, m)))
