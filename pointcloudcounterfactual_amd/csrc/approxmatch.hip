@@ -18,15 +18,21 @@
 //                                                | registers, summing them in the reference's order
 //   exp via __expf(level*d2)                     | v_exp_f32((level*log2e)*d2): level is a power of 4, so
 //                                                | the single rounded product is the same real number
-//   matchcost / grad re-read match 3x            | cost: one read; grads: one read each, deterministic
-//                                                | two-stage reductions (no float atomics)
-//   every pass evaluates all n*m pairs           | both clouds are Morton-sorted once per call (LDS bitonic
-//                                                | sort); at the fine levels a wave skips a 16-candidate
-//                                                | block when the box distance to its owner tile makes every
-//                                                | exp2(level*d2) underflow to exactly 0 (same result, less work)
+//   matchcost / grad re-read match 3x            | materialising entry points: cost accumulated by the pass that
+//                                                | writes match, both gradients from ONE read; the Python-level
+//                                                | match_cost never stores match at all (am_pair_kernel: cost and
+//                                                | gradients straight from registers, pcc_match_cost)
+//   every pass evaluates all n*m pairs           | only terms that are not EXACTLY zero in float32: both clouds are
+//                                                | Hilbert-sorted once per call (register bitonic sort); at the
+//                                                | fine levels (64-owner group, 16-candidate block) pairs whose box
+//                                                | distance makes every exp2(level*d2) underflow are skipped
+//                                                | (V_CULL), and points whose capacity is used up drop out as
+//                                                | candidates (V_CCAND / V_CLIST) and as owners (V_COWN)
+//   one stream, one block per sample             | a large batch runs as two half-batch lanes on two streams so
+//                                                | that the dependent launch chains fill each other's bubbles
 //
-// Rooflines: the 19 phase launches and the materialise pass are f32-VALU/transcendental
-// bound (10 / 14 / 60 issue slots per pair); matchcost and the two gradient kernels are HBM bound
+// Rooflines: the 19 phase launches, am_pair_kernel and the materialise pass are f32-VALU /
+// transcendental bound; matchcost and the fused gradient kernel of the materialising path are HBM bound
 // (one read of match each).
 #include "pcc_common.hpp"
 
