@@ -21,6 +21,7 @@ namespace {
 
 constexpr int kCap = 16;     // FIFO slots per lane
 constexpr int kCH = 2048;    // candidates staged per chunk (small-c kernel)
+constexpr int kTT128 = 1;    // tiles per stage of the 128-channel MFMA instantiation
 
 template <int K, int S>
 struct SmallLayout {
@@ -158,22 +159,23 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(int c, int n, const float *
     sq[(size_t)smp * n + i] = s;
 }
 
-template <int K, int CP /* padded channels, multiple of 2, <= 128 */>
-__global__ __launch_bounds__(256) void knn_mfma_kernel(int c, int n, int k, const float *__restrict__ x,
+template <int K, int CP /* padded channels, multiple of 2, <= 128 */, int TT /* 32-candidate tiles per stage */>
+__global__ __launch_bounds__(256, CP >= 128 ? 2 : 1) void knn_mfma_kernel(int c, int n, int k, const float *__restrict__ x,
                                                         const float *__restrict__ sq,
                                                         int64_t *__restrict__ indices) {
     constexpr int T = 256;
     constexpr int KS = CP / 2;  // MFMA k-steps (32x32x2)
-    constexpr int tile_bytes = CP * 32 * 4;
+    constexpr int TW = 32 * TT;  // candidates per stage
+    constexpr int tile_bytes = CP * TW * 4;
     constexpr int buf_bytes = 2 * kCap * T * 4;
     constexpr int merge_bytes = 2 * 8 * K * 32 * 4;  // [wave(4)][half(2)][K][32 queries]
-    constexpr int main_bytes = 2 * tile_bytes + 2 * 32 * 4 + buf_bytes;
+    constexpr int main_bytes = 2 * tile_bytes + 2 * TW * 4 + buf_bytes;
     constexpr int bytes = main_bytes > merge_bytes ? main_bytes : merge_bytes;
     __shared__ __attribute__((aligned(16))) unsigned char smem[bytes];
-    float *tile = reinterpret_cast<float *>(smem);                       // [2][CP][32]
-    float *tsq = reinterpret_cast<float *>(smem + 2 * tile_bytes);      // [2][32]
-    float *buf_d = reinterpret_cast<float *>(smem + 2 * tile_bytes + 2 * 32 * 4);
-    int *buf_i = reinterpret_cast<int *>(smem + 2 * tile_bytes + 2 * 32 * 4 + kCap * T * 4);
+    float *tile = reinterpret_cast<float *>(smem);                       // [2][CP][TW]
+    float *tsq = reinterpret_cast<float *>(smem + 2 * tile_bytes);      // [2][TW]
+    float *buf_d = reinterpret_cast<float *>(smem + 2 * tile_bytes + 2 * TW * 4);
+    int *buf_i = reinterpret_cast<int *>(smem + 2 * tile_bytes + 2 * TW * 4 + kCap * T * 4);
     float *mrg_d = reinterpret_cast<float *>(smem);
     int *mrg_i = reinterpret_cast<int *>(smem + 8 * K * 32 * 4);
 
@@ -198,37 +200,78 @@ __global__ __launch_bounds__(256) void knn_mfma_kernel(int c, int n, int k, cons
     pcc::BufferedTopK<K, kCap, T> tk;
     tk.init(buf_d, buf_i, tid);
 
-    const int ntiles = (n + 31) / 32;
-    auto stage = [&](int t, int slot) {
-        float *dst = tile + slot * CP * 32;
-        const int j0 = t * 32;
-        for (int e = tid; e < CP * 32; e += T) {
-            const int ch = e >> 5, j = e & 31;
-            dst[e] = (ch < c && j0 + j < n) ? xb[(size_t)ch * n + j0 + j] : 0.f;
+    const int nstages = (n + TW - 1) / TW;
+    // Staging is software-pipelined by hand: the global loads of stage t+1 are all issued (unconditional, clamped
+    // addresses; the select happens on the value) BEFORE the MFMAs of stage t and land in LDS after them.  Written as
+    // a plain conditional copy loop the compiler emitted load -> s_waitcnt vmcnt(0) -> ds_write per element, i.e. one
+    // exposed memory round trip per element (the kernel spent most of its time there).
+    constexpr int E = CP * TW / T;  // elements per thread per stage
+    static_assert(CP * TW % T == 0, "stage size must be a multiple of the workgroup");
+    float pre[E], pre_sq = 0.f;
+    auto fetch = [&](int t) {
+        const int j0 = t * TW;
+#pragma unroll
+        for (int i = 0; i < E; i++) {
+            const int e = tid + i * T;
+            const int ch = e / TW, j = e - ch * TW;
+            const bool ok = ch < c && j0 + j < n;
+            const float v = xb[(size_t)min(ch, c - 1) * n + min(j0 + j, n - 1)];
+            pre[i] = ok ? v : 0.f;
         }
-        if (tid < 32) tsq[slot * 32 + tid] = (j0 + tid < n) ? sqb[j0 + tid] : __builtin_inff();
+        if (tid < TW) {
+            const float v = sqb[min(j0 + tid, n - 1)];
+            pre_sq = (j0 + tid < n) ? v : __builtin_inff();
+        }
     };
-    stage(0, 0);
+    auto commit = [&](int slot) {
+        float *dst = tile + slot * CP * TW;
+#pragma unroll
+        for (int i = 0; i < E; i++) dst[tid + i * T] = pre[i];
+        if (tid < TW) tsq[slot * TW + tid] = pre_sq;
+    };
+    fetch(0);
+    commit(0);
     __syncthreads();
-    for (int t = 0; t < ntiles; t++) {
+    for (int t = 0; t < nstages; t++) {
         const int slot = t & 1;
-        if (t + 1 < ntiles) stage(t + 1, slot ^ 1);
-        const float *cur = tile + slot * CP * 32;
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (t + 1 < nstages) fetch(t + 1);
+        const float *cur = tile + slot * CP * TW;
+        // TT independent accumulator chains: a dependent MFMA cannot issue before the previous one has left the
+        // matrix pipe, so one chain per wave leaves the pipe idle half of the time (measured 166 cycles per
+        // v_mfma_f32_32x32x2_f32 against the 64 it occupies)
+        f32x16 acc[TT];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
-            // A operand: candidate[row = lane&31][k = 2*ks + half]
-            const float a = cur[(2 * ks + half) * 32 + col];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[ks], acc, 0, 0, 0);
-        }
-        if (tk.must_flush(16)) tk.flush();
+        for (int u = 0; u < TT; u++)
+            acc[u] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // A operands are read from LDS eight k-steps ahead of the MFMAs that consume them (one ds_read + full wait
+        // per MFMA left the matrix pipe idle for the LDS latency every step)
+        constexpr int KB = KS < 4 ? KS : 4;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;  // candidate inside the tile
-            // reference CPU path: dist = -2*dot ; dist += |xj|^2 (column term) ; dist += |xi|^2 (row term)
-            const float d = (-2.0f * acc[r] + tsq[slot * 32 + row]) + sq_q;
-            tk.offer(d, t * 32 + row);
+        for (int ks0 = 0; ks0 < KS; ks0 += KB) {
+            float av[KB][TT];
+#pragma unroll
+            for (int kk = 0; kk < KB; kk++)
+#pragma unroll
+                for (int u = 0; u < TT; u++)
+                    av[kk][u] = cur[(2 * (ks0 + kk) + half) * TW + u * 32 + col];  // candidate[row = lane&31][k] of sub-tile u
+#pragma unroll
+            for (int kk = 0; kk < KB; kk++)
+#pragma unroll
+                for (int u = 0; u < TT; u++)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][u], bq[ks0 + kk], acc[u], 0, 0, 0);
         }
+#pragma unroll
+        for (int u = 0; u < TT; u++) {
+            if (tk.must_flush(16)) tk.flush();
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // candidate inside the stage
+                // reference CPU path: dist = -2*dot ; dist += |xj|^2 (column term) ; dist += |xi|^2 (row term)
+                const float d = (-2.0f * acc[u][r] + tsq[slot * TW + row]) + sq_q;
+                tk.offer(d, t * TW + row);
+            }
+        }
+        if (t + 1 < nstages) commit(slot ^ 1);
         __syncthreads();
     }
     tk.flush();
@@ -270,11 +313,13 @@ template <int K>
 int launch_mfma(int b, int c, int n, int k, const float *x, const float *sq, int64_t *indices, hipStream_t st) {
     pcc::ProfScope prof("knn_mfma_kernel", st);
     const dim3 grid(pcc::ceil_div(n, 128), b);
-    if (c <= 8) hipLaunchKernelGGL((knn_mfma_kernel<K, 8>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
-    else if (c <= 16) hipLaunchKernelGGL((knn_mfma_kernel<K, 16>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
-    else if (c <= 32) hipLaunchKernelGGL((knn_mfma_kernel<K, 32>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
-    else if (c <= 64) hipLaunchKernelGGL((knn_mfma_kernel<K, 64>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
-    else hipLaunchKernelGGL((knn_mfma_kernel<K, 128>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
+    // two 32-candidate tiles (two accumulator chains) per stage while the double-buffered tiles leave room for two
+    // workgroups per CU; 128 channels keep one
+    if (c <= 8) hipLaunchKernelGGL((knn_mfma_kernel<K, 8, 1>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
+    else if (c <= 16) hipLaunchKernelGGL((knn_mfma_kernel<K, 16, 1>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
+    else if (c <= 32) hipLaunchKernelGGL((knn_mfma_kernel<K, 32, 1>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
+    else if (c <= 64) hipLaunchKernelGGL((knn_mfma_kernel<K, 64, 1>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
+    else hipLaunchKernelGGL((knn_mfma_kernel<K, 128, kTT128>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
     return PCC_OK;
 }
 
