@@ -34,6 +34,9 @@ def main() -> None:
     ap.add_argument('--batch-per-gpu', type=int, default=32)
     ap.add_argument('--points', type=int, default=2048)
     ap.add_argument('--unfused', action='store_true', help='compose EdgeConv as the reference does ([B,2C,N,k] tensor)')
+    ap.add_argument('--graph', action='store_true',
+                    help='capture one step into a hipGraph (torch.cuda.CUDAGraph) and replay it: the step is ~1500 launches, '
+                         'a third of its wall time is launch gaps')
     args = ap.parse_args()
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -61,6 +64,8 @@ def main() -> None:
         model.train()
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if dist is not None else model
         opt = harness.make_optimizer(model)
+        if args.graph:  # the optimiser state must live on the device to be captured
+            opt = torch.optim.AdamW(model.parameters(), lr=4e-3, weight_decay=1e-3, capturable=True)
 
         def step() -> None:
             opt.zero_grad(set_to_none=True)
@@ -84,6 +89,20 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.graph:
+        if dist is not None:
+            raise SystemExit('--graph is a single-GPU measurement')
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        step = graph.replay  # noqa: F811
     for _ in range(args.warmup):
         step()
     sync()
@@ -109,6 +128,7 @@ def main() -> None:
                        'global_batch': args.batch_per_gpu * world,
                        'parallelism': f'dp{world}' + (' (DDP all-reduce over RCCL)' if args.mode == 'train' else ' (no collective)')},
             'edgeconv': 'unfused (reference composition)' if args.unfused else 'fused (no [B,2C,N,k] tensor)',
+            'hipgraph': bool(args.graph),
             'peak_mem_gib': torch.cuda.max_memory_allocated() / 2**30,
         }), flush=True)
     if dist is not None:
