@@ -6,6 +6,8 @@
 // load for all channels of a block; the backward scatter accumulates into per-workgroup LDS bins (no global
 // atomics).
 #include "pcc_common.hpp"
+
+#include <cstdlib>
 #include "pcc_neighbour.h"
 
 namespace {
@@ -180,6 +182,113 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(int c, int n, int k, 
     }
 }
 
+// ---- neighbour-sum backward without per-edge float atomics ------------------------------------------------------
+// grad_x[b,c,t] = sum over edges (i -> t) of g[b,c,i].  ds_add_f32 costs ~3.5 cycles per LANE (measured), 35x a
+// ds_read, and the per-edge scatter above issues b*c*n*k of them (105 M at B=32, C=64, N=2048, k=25: 1 ms).  Here the
+// edge list of a sample is first sorted by TARGET (counting sort in LDS with integer atomics, once per call, shared
+// by all channels), then every wave streams 64 sorted edges at a time, gathers g[c][source] from the LDS-staged rows,
+// runs a segmented prefix sum over equal targets (shuffles; the segment structure is computed once per 64 edges and
+// reused by the CB channels) and only the last lane of every segment adds into the LDS bin: ~(n + n*k/64) float
+// atomics per channel instead of n*k, never two lanes of one instruction on the same bin.
+// The order of the edges inside a target's segment comes from integer atomics: like the scatter above (and torch's
+// scatter_add) the float summation order is not fixed.
+// rev[b][n*k] = source point (low 16 bits) | target point (high 16 bits), sorted by target; n <= 65536.
+__global__ __launch_bounds__(1024) void edge_sort_kernel(int n, int k, const int64_t *__restrict__ indices,
+                                                          unsigned *__restrict__ rev) {
+    extern __shared__ __attribute__((aligned(16))) int cur[];  // [n] counts, then write cursors
+    __shared__ int wave_tot[16];
+    const int smp = blockIdx.x, tid = threadIdx.x, T = 1024, lane = tid & 63, w = tid >> 6;
+    const size_t nk = (size_t)n * k;
+    const int64_t *ib = indices + (size_t)smp * nk;
+    unsigned *out = rev + (size_t)smp * nk;
+    for (int i = tid; i < n; i += T) cur[i] = 0;
+    __syncthreads();
+    for (size_t e = tid; e < nk; e += T) atomicAdd(&cur[(int)ib[e]], 1);
+    __syncthreads();
+    // exclusive scan of the n counts: every thread owns a contiguous run
+    const int per = (n + T - 1) / T;
+    const int beg = min(tid * per, n), end = min(beg + per, n);
+    int mine = 0;
+    for (int i = beg; i < end; i++) mine += cur[i];
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        incl += lane >= off ? v : 0;
+    }
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int i = 0; i < w; i++) before += wave_tot[i];
+    int run = before + incl - mine;
+    for (int i = beg; i < end; i++) {
+        const int cnt = cur[i];
+        cur[i] = run;
+        run += cnt;
+    }
+    __syncthreads();
+    for (size_t e = tid; e < nk; e += T) {
+        const int t = (int)ib[e];
+        const int pos = atomicAdd(&cur[t], 1);
+        out[pos] = (unsigned)(e / k) | ((unsigned)t << 16);
+    }
+}
+
+template <int CB>
+__global__ __launch_bounds__(1024) void nbrsum_bwd_sorted_kernel(int c, int n, int k, const unsigned *__restrict__ rev,
+                                                                  const float *__restrict__ g,
+                                                                  float *__restrict__ grad_x) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // rows [CB][n] | bins [CB][n]
+    float *rows = lds, *bins = lds + (size_t)CB * n;
+    const int smp = blockIdx.y, c0 = blockIdx.x * CB;
+    const int tid = threadIdx.x, T = 1024, lane = tid & 63;
+    const size_t nk = (size_t)n * k;
+    const unsigned *rb = rev + (size_t)smp * nk;
+    for (int i = tid; i < CB * n; i += T) {
+        const int cc = i / n, p = i - cc * n;
+        rows[i] = c0 + cc < c ? g[((size_t)smp * c + c0 + cc) * n + p] : 0.f;
+        bins[i] = 0.f;
+    }
+    __syncthreads();
+    const size_t span = (nk + 63) / 64 * 64;  // whole waves enter the loop (shuffles need every lane)
+    for (size_t e = tid; e < span; e += T) {
+        const bool valid = e < nk;
+        const unsigned r = valid ? rb[e] : 0xffffffffu;
+        const int src = (int)(r & 0xffffu) % n;  // (an invalid lane reads a harmless in-range address)
+        const int t = valid ? (int)(r >> 16) : -1;
+        // segment structure of these 64 edges (sorted by target): shared by the CB channels
+        bool same[6];
+#pragma unroll
+        for (int s6 = 0; s6 < 6; s6++) {
+            const int off = 1 << s6;
+            const int tp = __shfl_up(t, off, 64);  // every lane takes part (no short-circuit: a lane masked off by
+            same[s6] = lane >= off && tp == t;     // `lane >= off &&` would hand garbage to the lanes reading it)
+        }
+        const int tn = __shfl_down(t, 1, 64);
+        const bool tail = valid && (lane == 63 || tn != t);
+        float v[CB];
+#pragma unroll
+        for (int cc = 0; cc < CB; cc++) v[cc] = valid ? rows[cc * n + src] : 0.f;
+#pragma unroll
+        for (int s6 = 0; s6 < 6; s6++) {
+#pragma unroll
+            for (int cc = 0; cc < CB; cc++) {
+                const float u = __shfl_up(v[cc], 1 << s6, 64);
+                v[cc] += same[s6] ? u : 0.f;
+            }
+        }
+        if (tail) {
+#pragma unroll
+            for (int cc = 0; cc < CB; cc++) atomicAdd(&bins[cc * n + t], v[cc]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < CB * n; i += T) {
+        const int cc = i / n, p = i - cc * n;
+        if (c0 + cc < c) grad_x[((size_t)smp * c + c0 + cc) * n + p] = bins[i];
+    }
+}
+
 // One wave per (b,c) row: max (first maximum), argmax and mean over n.
 __global__ __launch_bounds__(256) void global_pool_kernel(int rows, int n, const float *__restrict__ x,
                                                            float *__restrict__ out_max, int32_t *__restrict__ argmax,
@@ -350,8 +459,48 @@ int pcc_neighbour_sum_bwd(int b, int c, int n, int k, const int64_t *indices, co
     if (int rc = check("neighbour_sum_bwd: bad size", b, c, n, k)) return rc;
     if (b == 0 || n == 0) return PCC_OK;
     if (!indices || !grad_out || !grad_x) return pcc::invalid("neighbour_sum_bwd: null pointer");
-    return scatter_bwd<3>(b, c, n, k, indices, nullptr, grad_out, grad_x, static_cast<hipStream_t>(stream),
-                          "scatter_lds_kernel<nbrsum>");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static const bool sorted_enabled = [] {  // PCC_NBRSUM_SCATTER=1: the per-edge atomic scatter (A/B measurements)
+        const char *e = std::getenv("PCC_NBRSUM_SCATTER");
+        return !(e && e[0] == '1');
+    }();
+    // sorted-edge schedule: needs 16-bit point ids and rows + bins of >= 1 channel in LDS
+    if (sorted_enabled && n <= 65536 && (size_t)n * 8 <= 128 * 1024 && (size_t)n * 4 <= 160 * 1024 - 256) {
+        unsigned *rev = nullptr;
+        if (hipMallocAsync(reinterpret_cast<void **>(&rev), (size_t)b * n * k * sizeof(unsigned), st) != hipSuccess) {
+            (void)hipGetLastError();
+            pcc::set_error(PCC_ENOMEM, "neighbour_sum_bwd: workspace hipMallocAsync failed");
+            return PCC_ENOMEM;
+        }
+        static bool attr_sort = [] {
+            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(edge_sort_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            return ok;
+        }();
+        (void)attr_sort;
+        {
+            pcc::ProfScope prof("edge_sort_kernel", st);
+            hipLaunchKernelGGL(edge_sort_kernel, dim3(b), dim3(1024), (size_t)n * sizeof(int), st, n, k, indices, rev);
+        }
+        int cb = 4;
+        while (cb > 1 && (size_t)2 * cb * n * sizeof(float) > 64 * 1024) cb >>= 1;
+        const size_t lds = (size_t)2 * cb * n * sizeof(float);
+        const dim3 grid(pcc::ceil_div(c, cb), b);
+        {
+            pcc::ProfScope prof("nbrsum_bwd_sorted_kernel", st);
+#define PCC_LAUNCH_S(CB)                                                                                                  do {                                                                                                                      static bool attr = [] {                                                                                                   const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(nbrsum_bwd_sorted_kernel<CB>),                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;             if (!ok) (void)hipGetLastError();                                                                                     return ok;                                                                                                        }();                                                                                                                  (void)attr;                                                                                                           hipLaunchKernelGGL((nbrsum_bwd_sorted_kernel<CB>), grid, dim3(1024), lds, st, c, n, k, rev, grad_out, grad_x);     } while (0)
+            switch (cb) {
+            case 4: PCC_LAUNCH_S(4); break;
+            case 2: PCC_LAUNCH_S(2); break;
+            default: PCC_LAUNCH_S(1); break;
+            }
+#undef PCC_LAUNCH_S
+        }
+        (void)hipFreeAsync(rev, st);
+        return pcc::check_launch("neighbour_sum_bwd(sorted)");
+    }
+    return scatter_bwd<3>(b, c, n, k, indices, nullptr, grad_out, grad_x, st, "scatter_lds_kernel<nbrsum>");
 }
 
 int pcc_neighbour_minmax_target(int b, int c, int n, int k, const float *x, const int64_t *indices, int64_t *tsel,
