@@ -78,11 +78,13 @@ int pcc_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2
  * (src/train/metrics_and_losses.py:21-47): loss[b] = mean_j dist1[b,j] + mean_k dist2[b,k] (`mean` != 0,
  * pykeops_chamfer) or the plain sums (`mean` == 0, torch_chamfer's scale).  pcc_chamfer_loss = pcc_nndistance + one
  * fixed-order reduction; pcc_chamfer_loss_grad = pcc_nndistancegrad with grad_dist1[b,:] = grad_loss[b] (/ n),
- * grad_dist2[b,:] = grad_loss[b] (/ m) formed inside the kernel. */
+ * grad_dist2[b,:] = grad_loss[b] (/ m) formed inside the kernel; grad_loss_stride is 1, or 0 when the upstream
+ * gradient is one scalar expanded over the batch (what `loss.sum().backward()` hands down). */
 int pcc_chamfer_loss(int b, int n, const float *xyz1, int m, const float *xyz2, int mean, float *loss, float *dist1,
                      int *idx1, float *dist2, int *idx2, pcc_stream_t stream);
 int pcc_chamfer_loss_grad(int b, int n, const float *xyz1, int m, const float *xyz2, const int *idx1, const int *idx2,
-                          const float *grad_loss, int mean, float *grad_xyz1, float *grad_xyz2, pcc_stream_t stream);
+                          const float *grad_loss, int grad_loss_stride, int mean, float *grad_xyz1, float *grad_xyz2,
+                          pcc_stream_t stream);
 
 /* ---- approximate EMD ---------------------------------------------------------------------------
  * Replaces `approxmatch` (reference approxmatch.cu:299-307; declared structural_loss.cpp:10).

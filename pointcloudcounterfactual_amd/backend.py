@@ -197,17 +197,24 @@ def ChamferLossGrad(set_d: torch.Tensor, set_q: torch.Tensor, idx1: torch.Tensor
     b, n, m = _sizes(set_d, set_q)
     grad1 = torch.empty((b, n, 3), dtype=torch.float32, device=set_d.device)
     grad2 = torch.empty((b, m, 3), dtype=torch.float32, device=set_d.device)
-    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (idx1, 'idx1'), (idx2, 'idx2'), (grad_loss, 'grad_loss')):
+    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (idx1, 'idx1'), (idx2, 'idx2')):
         _check_input(t, name)
+    if grad_loss.device.type != 'cuda':
+        raise RuntimeError('grad_loss must be a CUDA tensor')
     for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (grad_loss, 'grad_loss')):
         _f32(t, name)
     _i32(idx1, 'idx1')
     _i32(idx2, 'idx2')
     if idx1.numel() != b * n or idx2.numel() != b * m or grad_loss.numel() != b:
         raise RuntimeError('ChamferLossGrad: idx / grad_loss shapes do not match the clouds')
+    # one scalar expanded over the batch (loss.sum().backward()) is read in place through stride 0: no copy kernel
+    stride = grad_loss.stride(0) if grad_loss.dim() == 1 and b > 1 else 1
+    if stride not in (0, 1):
+        grad_loss = grad_loss.contiguous()
+        stride = 1
     with torch.cuda.device(set_d.device):
         _lib.check(_L.pcc_chamfer_loss_grad(b, n, set_d.data_ptr(), m, set_q.data_ptr(), idx1.data_ptr(),
-                                            idx2.data_ptr(), grad_loss.data_ptr(), int(mean), grad1.data_ptr(),
+                                            idx2.data_ptr(), grad_loss.data_ptr(), int(stride), int(mean), grad1.data_ptr(),
                                             grad2.data_ptr(), _stream(set_d)), 'ChamferLossGrad')
     return [grad1, grad2]
 

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *_
                                                             const float *__restrict__ gd2,
                                                             const int *__restrict__ idx2,
                                                             float *__restrict__ grad1, float *__restrict__ grad2,
-                                                            int P, const float *__restrict__ gloss, int mean) {
+                                                            int P, const float *__restrict__ gloss, int mean, int gloss_stride) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const int smp = blockIdx.y, p = blockIdx.x;
     const int tid = threadIdx.x, T = 256;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *_
     // spread over the points (loss = sum or mean of the distances)
     const float *g1 = gloss ? nullptr : gd1 + (size_t)smp * n;
     const float *g2 = gloss ? nullptr : gd2 + (size_t)smp * m;
-    const float gs = gloss ? gloss[smp] : 0.f;
+    const float gs = gloss ? gloss[(size_t)smp * gloss_stride] : 0.f;  // stride 0: one value for the batch (an expanded scalar)
     const float gs1 = mean ? gs / (float)n : gs, gs2 = mean ? gs / (float)m : gs;
     // direct terms (one owner per destination -> plain LDS stores)
     for (int j = j0 + tid; j < j1; j += T) {
@@ -272,8 +272,8 @@ __global__ __launch_bounds__(256) void chamfer_reduce_kernel(int n, int m, const
 }
 
 int launch_bwd(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad_dist1, const int *idx1,
-               const float *grad_dist2, const int *idx2, const float *gloss, int mean, float *grad_xyz1,
-               float *grad_xyz2, hipStream_t st) {
+               const float *grad_dist2, const int *idx2, const float *gloss, int mean, int gloss_stride,
+               float *grad_xyz1, float *grad_xyz2, hipStream_t st) {
     // P destination ranges per sample: ~512 workgroups on the chip, each range pair <= 48 KiB of LDS.
     long long P = std::max<long long>(1, pcc::ceil_div(512, b));
     P = std::min<long long>(P, std::max(1, std::min(n, m) / 64));
@@ -284,7 +284,7 @@ int launch_bwd(int b, int n, const float *xyz1, int m, const float *xyz2, const 
     {
         pcc::ProfScope prof("nn_bwd_range_kernel", st);
         hipLaunchKernelGGL(nn_bwd_range_kernel, dim3((unsigned)P, (unsigned)b), dim3(256), lds, st, n, xyz1, m, xyz2,
-                           grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, (int)P, gloss, mean);
+                           grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, (int)P, gloss, mean, gloss_stride);
     }
     return pcc::check_launch("nndistancegrad");
 }
@@ -349,7 +349,7 @@ int pcc_nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2
     if (n == 0 || m == 0) return pcc::invalid("nndistancegrad: one cloud is empty");
     if (!xyz1 || !xyz2 || !grad_dist1 || !idx1 || !grad_dist2 || !idx2 || !grad_xyz1 || !grad_xyz2)
         return pcc::invalid("nndistancegrad: null pointer");
-    return launch_bwd(b, n, xyz1, m, xyz2, grad_dist1, idx1, grad_dist2, idx2, nullptr, 0, grad_xyz1, grad_xyz2,
+    return launch_bwd(b, n, xyz1, m, xyz2, grad_dist1, idx1, grad_dist2, idx2, nullptr, 0, 1, grad_xyz1, grad_xyz2,
                       static_cast<hipStream_t>(stream));
 }
 
@@ -364,14 +364,16 @@ int pcc_chamfer_loss(int b, int n, const float *xyz1, int m, const float *xyz2, 
 }
 
 int pcc_chamfer_loss_grad(int b, int n, const float *xyz1, int m, const float *xyz2, const int *idx1, const int *idx2,
-                          const float *grad_loss, int mean, float *grad_xyz1, float *grad_xyz2, pcc_stream_t stream) {
+                          const float *grad_loss, int grad_loss_stride, int mean, float *grad_xyz1, float *grad_xyz2,
+                          pcc_stream_t stream) {
     pcc::clear_error();
     if (b < 0 || n < 0 || m < 0) return pcc::invalid("chamfer_loss_grad: negative size");
     if (b == 0 || (n == 0 && m == 0)) return PCC_OK;
     if (n == 0 || m == 0) return pcc::invalid("chamfer_loss_grad: one cloud is empty");
     if (!xyz1 || !xyz2 || !idx1 || !idx2 || !grad_loss || !grad_xyz1 || !grad_xyz2)
         return pcc::invalid("chamfer_loss_grad: null pointer");
-    return launch_bwd(b, n, xyz1, m, xyz2, nullptr, idx1, nullptr, idx2, grad_loss, mean, grad_xyz1, grad_xyz2,
+    if (grad_loss_stride != 0 && grad_loss_stride != 1) return pcc::invalid("chamfer_loss_grad: grad_loss stride must be 0 or 1");
+    return launch_bwd(b, n, xyz1, m, xyz2, nullptr, idx1, nullptr, idx2, grad_loss, mean, grad_loss_stride, grad_xyz1, grad_xyz2,
                       static_cast<hipStream_t>(stream));
 }
 

@@ -117,7 +117,8 @@ class ChamferFunction(Function):
     @staticmethod
     def backward(ctx: Any, *grad_outputs: Any) -> Any:
         t1, t2, idx1, idx2 = ctx.saved_tensors
-        grad1, grad2 = backend.ChamferLossGrad(t1, t2, idx1, idx2, grad_outputs[0].contiguous().float(), ctx.mean)
+        g = grad_outputs[0]
+        grad1, grad2 = backend.ChamferLossGrad(t1, t2, idx1, idx2, g if g.dtype == torch.float32 else g.float(), ctx.mean)
         return grad1, grad2, None
 
 
