@@ -90,6 +90,21 @@ int pcc_pair_sqdist_sum(int b, int np, int nq, int d, const float *p, const floa
 int pcc_pair_sqdist_sum_bwd(int b, int np, int nq, int d, const float *p, const float *q, const float *grad_out,
                             float *grad_p, float *grad_q, pcc_stream_t stream);
 
+/* ---- BatchNorm1d + ReLU (+ channel-repeated residual) over [b,c,n] --------------------------------------------------
+ * The tail of the reference's PointsConv block (src/module/layers.py:159-166: conv -> BatchNorm1d -> activation ->
+ * `+ x.repeat_interleave(r, 1)[:, :c]`), fused into streaming passes: pcc_bn_stats (training: per-channel mean and
+ * biased variance over b*n, accumulated in double), pcc_bn_relu_res_fwd
+ *   y[b,ch,i] = max(0, (z - mean[ch]) * rsqrt(var[ch] + eps) * gamma[ch] + beta[ch]) + res[b, ch / r, i]   (res may be NULL)
+ * and pcc_bn_relu_bwd (grad_z, grad_gamma[c], grad_beta[c]; `training` = the statistics depend on z).  The gradient of
+ * the residual operand is grad_y summed over each group of r channels (left to the caller).  b*c <= 65535. */
+int pcc_bn_stats(int b, int c, int n, const float *z, float *mean, float *var, pcc_stream_t stream);
+int pcc_bn_relu_res_fwd(int b, int c, int n, const float *z, const float *mean, const float *var, float eps,
+                        const float *gamma, const float *beta, const float *res, int res_c, int r, float *y,
+                        pcc_stream_t stream);
+int pcc_bn_relu_bwd(int b, int c, int n, const float *z, const float *mean, const float *var, float eps,
+                    const float *gamma, const float *beta, const float *grad_y, int training, float *grad_z,
+                    float *grad_gamma, float *grad_beta, pcc_stream_t stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -62,6 +62,9 @@ ABI: dict[str, tuple[object, list[object]]] = {
     'pcc_pair_argmin': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     'pcc_pair_sqdist_sum': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     'pcc_pair_sqdist_sum_bwd': (_int, [_int, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'pcc_bn_stats': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp]),
+    'pcc_bn_relu_res_fwd': (_int, [_int, _int, _int, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _int, _int, _vp, _vp]),
+    'pcc_bn_relu_bwd': (_int, [_int, _int, _int, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     # include/pcc_emd.h
     'pcc_auction_forward': (_int, [_int, _int, _vp, _vp, ctypes.c_float, _int, _vp, _vp, _vp]),
     'pcc_auction_backward': (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),

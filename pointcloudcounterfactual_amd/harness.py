@@ -26,6 +26,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from pointcloudcounterfactual_amd import _lib
 from pointcloudcounterfactual_amd import neighbour_ops as ops
 from pointcloudcounterfactual_amd.edgeconv import FusedEdgeConv
 from pointcloudcounterfactual_amd.losses import chamfer, match_cost
@@ -42,6 +43,49 @@ class EdgeConv(nn.Module):
         return self.act(self.bn(self.conv(x)))
 
 
+class _BNReLURes(torch.autograd.Function):
+    """``relu(batch_norm(z)) + res.repeat_interleave(r, 1)[:, :C]`` over ``[B,C,N]`` in two streaming passes forward and
+    two backward (``csrc/bnact.hip``) instead of PyTorch's BatchNorm + threshold + add kernels; same values as the
+    composition (tests/test_gpu_harness.py).  ``mean`` / ``var`` are the batch statistics (training) or the running
+    ones (eval)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, res, r, mean, var, eps, training):  # noqa: ANN001
+        b, c, n = z.shape
+        y = torch.empty_like(z)
+        st = torch.cuda.current_stream(z.device).cuda_stream
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.lib.pcc_bn_relu_res_fwd(b, c, n, z.data_ptr(), mean.data_ptr(), var.data_ptr(), float(eps),
+                                                    gamma.data_ptr(), beta.data_ptr(),
+                                                    res.data_ptr() if res is not None else None,
+                                                    res.shape[1] if res is not None else 0, int(r), y.data_ptr(), st),
+                       'bn_relu_res_fwd')
+        ctx.save_for_backward(z, gamma, beta, mean, var)
+        ctx.eps, ctx.training, ctx.r = float(eps), bool(training), int(r)
+        ctx.res_shape = None if res is None else tuple(res.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):  # noqa: ANN001
+        z, gamma, beta, mean, var = ctx.saved_tensors
+        b, c, n = z.shape
+        gy = gy.contiguous()
+        dz = torch.empty_like(z)
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(beta)
+        st = torch.cuda.current_stream(z.device).cuda_stream
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.lib.pcc_bn_relu_bwd(b, c, n, z.data_ptr(), mean.data_ptr(), var.data_ptr(), ctx.eps,
+                                                gamma.data_ptr(), beta.data_ptr(), gy.data_ptr(), int(ctx.training),
+                                                dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), st), 'bn_relu_bwd')
+        dres = None
+        if ctx.res_shape is not None and ctx.needs_input_grad[3]:
+            r, used = ctx.r, c // ctx.r
+            g = gy.view(b, used, r, n).sum(2) if r > 1 else gy
+            dres = g if used == ctx.res_shape[1] else F.pad(g, (0, 0, 0, ctx.res_shape[1] - used))
+        return dz, dgamma, dbeta, dres, None, None, None, None, None
+
+
 class PointsConv(nn.Module):
     def __init__(self, cin: int, cout: int, act: nn.Module | None = None, bn: bool = True, residual: bool = False) -> None:
         super().__init__()
@@ -51,8 +95,38 @@ class PointsConv(nn.Module):
         self.residual = residual
         self.cin, self.cout = cin, cout
 
+    def _fused_tail(self, z: torch.Tensor, x: torch.Tensor) -> torch.Tensor | None:
+        """BatchNorm1d + ReLU (+ residual) through the fused HIP passes when the block has exactly that shape."""
+        bn = self.bn
+        r = self.cout // self.cin + 1
+        if not (isinstance(bn, nn.BatchNorm1d) and isinstance(self.act, nn.ReLU) and z.is_cuda and z.dtype == torch.float32
+                and z.is_contiguous() and z.shape[0] * z.shape[1] <= 65535 and bn.affine and bn.track_running_stats
+                and (not self.residual or (self.cout % r == 0 and x.is_contiguous()))):
+            return None
+        b, c, n = z.shape
+        if self.training:
+            mean = torch.empty(c, device=z.device, dtype=torch.float32)
+            var = torch.empty_like(mean)
+            with torch.cuda.device(z.device):
+                _lib.check(_lib.lib.pcc_bn_stats(b, c, n, z.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                                 torch.cuda.current_stream(z.device).cuda_stream), 'bn_stats')
+            with torch.no_grad():  # running statistics exactly as nn.BatchNorm1d keeps them (unbiased variance)
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                cnt = b * n
+                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1 - m).add_(var, alpha=m * cnt / max(cnt - 1, 1))
+                bn.num_batches_tracked += 1
+        else:
+            mean, var = bn.running_mean, bn.running_var
+        res = x if self.residual else None
+        return _BNReLURes.apply(z, bn.weight, bn.bias, res, r if self.residual else 1, mean, var, bn.eps, self.training)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        y = self.act(self.bn(self.conv(x)))
+        z = self.conv(x)
+        y = self._fused_tail(z, x)
+        if y is not None:
+            return y
+        y = self.act(self.bn(z))
         if self.residual:
             # layers.py:164-166: y + x.repeat_interleave(r, 1)[:, :cout] with r = cout // cin + 1, i.e. output channel o
             # receives input channel o // r.  Same values without materialising the r-fold repeated tensor (536 MB for the

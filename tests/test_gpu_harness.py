@@ -42,3 +42,39 @@ def test_inference_pipeline(cuda):
         out = model(ref_t)
         metric = chamfer(out['recon'], ref_t) + match_cost(out['recon'], ref_t)
     assert logits.shape == (2, 40) and metric.shape == (2,) and torch.isfinite(metric).all()
+
+
+@pytest.mark.parametrize('cin,cout,residual,n', [(64, 64, True, 256), (64, 16, True, 300), (32, 48, False, 128), (8, 8, True, 77)])
+@pytest.mark.parametrize('training', [True, False])
+def test_points_conv_fused_tail_matches_torch(cuda, cin, cout, residual, n, training):
+    """PointsConv with the fused BatchNorm1d + ReLU (+ residual) passes (csrc/bnact.hip) == the PyTorch composition of
+    the reference block (layers.py:159-166): outputs, input / parameter gradients and the running statistics."""
+    import copy
+
+    from pointcloudcounterfactual_amd import harness
+
+    torch.manual_seed(cin * 7 + cout)
+    fused = harness.PointsConv(cin, cout, torch.nn.ReLU(inplace=True), residual=residual).to(cuda)
+    with torch.no_grad():
+        fused.bn.weight.uniform_(0.5, 1.5)
+        fused.bn.bias.uniform_(-0.5, 0.5)
+        fused.bn.running_mean.uniform_(-0.2, 0.2)
+        fused.bn.running_var.uniform_(0.5, 1.5)
+    plain = copy.deepcopy(fused)
+    plain._fused_tail = lambda z, x: None  # the PyTorch composition
+    fused.train(training)
+    plain.train(training)
+    x1 = torch.randn(3, cin, n, device=cuda, requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    y1, y2 = fused(x1), plain(x2)
+    torch.testing.assert_close(y1, y2, rtol=1e-4, atol=1e-5)
+    w = torch.randn_like(y1)
+    (y1 * w).sum().backward()
+    (y2 * w).sum().backward()
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-3, atol=1e-4)
+    for (n1, p1), (_n2, p2) in zip(fused.named_parameters(), plain.named_parameters()):
+        scale = float(p2.grad.abs().max()) + 1e-6
+        torch.testing.assert_close(p1.grad, p2.grad, rtol=1e-3, atol=1e-4 * scale, msg=n1)
+    torch.testing.assert_close(fused.bn.running_mean, plain.bn.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(fused.bn.running_var, plain.bn.running_var, rtol=1e-5, atol=1e-6)
+    assert int(fused.bn.num_batches_tracked) == int(plain.bn.num_batches_tracked)
