@@ -523,3 +523,19 @@ def test_random_shape_sweep(cuda, oracle_mod):
         scale = max(float(g1.abs().max()), float(g2.abs().max()), 1e-30)
         np.testing.assert_allclose(h1.cpu().numpy(), g1.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale, err_msg=str((b, n, m)))
         np.testing.assert_allclose(h2.cpu().numpy(), g2.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale, err_msg=str((b, n, m)))
+
+
+def test_lanes_with_odd_batch_and_unequal_clouds(cuda):
+    """A batch that splits into two unequal lanes (9 samples -> 4 + 5) with n != m: every sample's cost and gradients
+    carry the bits of the same sample run on its own (one lane, one stream)."""
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(313, 9, 4099, 3000)
+    t1, t2 = _dev(a, cuda), _dev(c, cuda)
+    cost, g1, g2 = backend.MatchCostImplicit(t1, t2, True)
+    match, _temp, mcost = backend.ApproxMatchCost(t1, t2)
+    for s in (0, 3, 4, 8):
+        cs, h1, h2 = backend.MatchCostImplicit(t1[s:s + 1].contiguous(), t2[s:s + 1].contiguous(), True)
+        assert torch.equal(cs, cost[s:s + 1]) and torch.equal(h1, g1[s:s + 1]) and torch.equal(h2, g2[s:s + 1]), s
+        ms, _ts, mc = backend.ApproxMatchCost(t1[s:s + 1].contiguous(), t2[s:s + 1].contiguous())
+        assert torch.equal(mc, mcost[s:s + 1]) and torch.equal(ms, match[s:s + 1]), s
