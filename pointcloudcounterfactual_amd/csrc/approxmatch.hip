@@ -80,6 +80,7 @@ constexpr float kZeroExp = 151.f; // exp2(x) == 0 exactly for x <= -150 (below t
 
 struct PhaseArgs {
     int n_own, n_cand, tiles, batch;   // tiles = ceil(n_own / (64 R))
+    int xcd;                           // XCD-aware block mapping (PCC_AM_NOXCD=1 turns it off)
     int own_n4, cand_n4, own_nb, cand_nb;
     const float *own_soa, *cand_soa;   // [b][3][n4] Hilbert-sorted coordinates
     const float *own_box, *cand_box;   // own: [b][ceil(n/64)][8] per 64 sorted points; cand: [b][nb][8] per 16 (min xyz,0,max xyz,0)
@@ -684,8 +685,29 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     // V_COWN packs the live owners into the low tiles: dispatch those first (tile-major order), so the workgroups
     // that have nothing to do and exit after the scan are not in front of the ones that carry the launch
     constexpr bool COWN = VAR == V_COWN;
-    const int smp = COWN ? (int)(blockIdx.x % a.batch) : (int)(blockIdx.x / a.tiles);
-    const int tile = COWN ? (int)(blockIdx.x / a.batch) : (int)(blockIdx.x - smp * a.tiles);
+    // XCD affinity (cdna_hip_programming.md T1): blocks with equal blockIdx % 8 share an XCD and its L2.  All workgroups
+    // of a sample stage the same candidate cloud at the same moment, so a sample's workgroups are given block ids of one
+    // residue class: its cloud crosses the fabric once per launch instead of once per XCD (a pure speed choice).
+    int smp, tile;
+    const int bid = (int)blockIdx.x, nwg = (int)gridDim.x;
+    if (COWN) {
+        if (a.xcd && a.batch % 8 == 0) {  // samples congruent to the XCD label, tile-major inside the class
+            const int per = a.batch / 8, i = bid / 8;
+            smp = (bid % 8) + 8 * (i % per);
+            tile = i / per;
+        } else {
+            smp = bid % a.batch;
+            tile = bid / a.batch;
+        }
+    } else {
+        int lid = bid;
+        if (a.xcd && nwg > 8) {  // bijective swizzle: the blocks of one residue class get a contiguous run of logical ids
+            const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+            lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+        }
+        smp = lid / a.tiles;
+        tile = lid - smp * a.tiles;
+    }
     am_phase_body<MODE, R, S, CH, VAR, false>(a, smp, tile, smem);
 }
 
@@ -1766,6 +1788,11 @@ template <int MODE, int R, int S>
 int launch_phase_rs(PhaseArgs a, int b, int var, hipStream_t st, const char *what) {
     a.tiles = pcc::ceil_div(a.n_own, 64 * R);
     a.batch = b;
+    static const int xcd_on = [] {
+        const char *e = std::getenv("PCC_AM_NOXCD");
+        return (e && e[0] == '1') ? 0 : 1;
+    }();
+    a.xcd = xcd_on;
     const long long grid = (long long)b * a.tiles;
     if (grid > 0x7fffffffLL) return pcc::invalid("approxmatch: grid too large");
     {
