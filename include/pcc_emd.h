@@ -28,7 +28,19 @@ extern "C" {
 int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, float eps, int iters, float *dist,
                         int *assignment, pcc_stream_t stream);
 
-/* emd_cuda_backward (emd_cuda.cu:283-315): grad_xyz1[b,n,3] = 2 grad_dist (xyz1 - xyz2[assignment]); overwritten. */
+/* Failure reporting of the cluster schedule (several workgroups per sample that meet at sample-local barriers): if a
+ * barrier times out -- a workgroup of the sample was never scheduled -- the kernel poisons its outputs (dist = NaN,
+ * unassigned points keep assignment -1) and raises a sticky per-device word.  The NEXT pcc_auction_forward /
+ * pcc_auction_backward on that device returns PCC_EINVAL with a message instead of starting, and
+ * pcc_auction_status() returns 1 (each of them clears the word).  Launches are asynchronous: synchronise the stream
+ * before asking.  Cluster launches issued on different streams are ordered one after the other by an event, so two of
+ * them never compete for residency.  pcc_auction_test_inject_failure() makes the next cluster launch start with its
+ * error word raised (test hook for the reporting path). */
+int pcc_auction_status(void);
+void pcc_auction_test_inject_failure(void);
+
+/* emd_cuda_backward (emd_cuda.cu:283-315): grad_xyz1[b,n,3] = 2 grad_dist (xyz1 - xyz2[assignment]); overwritten.
+ * An assignment outside [0, n) contributes a zero gradient. */
 int pcc_auction_backward(int b, int n, const float *xyz1, const float *xyz2, const float *grad_dist,
                          const int *assignment, float *grad_xyz1, pcc_stream_t stream);
 

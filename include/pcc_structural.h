@@ -86,6 +86,16 @@ int pcc_chamfer_loss_grad(int b, int n, const float *xyz1, int m, const float *x
                           const float *grad_loss, int grad_loss_stride, int mean, float *grad_xyz1, float *grad_xyz2,
                           pcc_stream_t stream);
 
+/* Backward of the reference's ChamferEMD reconstruction loss (src/train/metrics_and_losses.py:70-79: Chamfer and
+ * match_cost on the same pair of clouds) in one launch: pcc_chamfer_loss_grad of grad_chamfer[b] plus the unscaled
+ * match_cost gradients emd_grad1[b,n,3] / emd_grad2[b,m,3] (as pcc_match_cost returns them) times grad_emd[b]
+ * (NULL = 1).  Strides as above (0 = one scalar for the batch).  Bit-identical to the two backward passes followed by
+ * autograd's gradient accumulation. */
+int pcc_chamfer_emd_grad(int b, int n, const float *xyz1, int m, const float *xyz2, const int *idx1, const int *idx2,
+                         const float *grad_chamfer, int grad_chamfer_stride, int mean, const float *emd_grad1,
+                         const float *emd_grad2, const float *grad_emd, int grad_emd_stride, float *grad_xyz1,
+                         float *grad_xyz2, pcc_stream_t stream);
+
 /* ---- approximate EMD ---------------------------------------------------------------------------
  * Replaces `approxmatch` (reference approxmatch.cu:299-307; declared structural_loss.cpp:10).
  *   xyz1[b,n,3], xyz2[b,m,3] -> match[b,m,n] (query-major), temp[b,2(n+m)] =

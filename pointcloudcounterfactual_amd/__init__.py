@@ -9,10 +9,11 @@ from pointcloudcounterfactual_amd.losses import (  # noqa: F401
     MatchCostFunction,
     NNDistanceFunction,
     chamfer,
+    chamfer_emd,
     match_cost,
     nn_distance,
     torch_chamfer,
 )
 
-__all__ = ['match_cost', 'nn_distance', 'chamfer', 'torch_chamfer', 'MatchCostFunction', 'NNDistanceFunction',
+__all__ = ['match_cost', 'nn_distance', 'chamfer', 'chamfer_emd', 'torch_chamfer', 'MatchCostFunction', 'NNDistanceFunction',
            'backend']

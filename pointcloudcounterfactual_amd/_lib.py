@@ -36,6 +36,7 @@ ABI: dict[str, tuple[object, list[object]]] = {
     'pcc_nndistancegrad': (_int, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcc_chamfer_loss': (_int, [_int, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcc_chamfer_loss_grad': (_int, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp]),
+    'pcc_chamfer_emd_grad': (_int, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     'approxmatch': (None, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     'pcc_approxmatch': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     'pcc_approxmatch_workspace_bytes': (ctypes.c_size_t, [_int, _int, _int]),
@@ -67,6 +68,8 @@ ABI: dict[str, tuple[object, list[object]]] = {
     'pcc_bn_relu_bwd': (_int, [_int, _int, _int, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
     # include/pcc_emd.h
     'pcc_auction_forward': (_int, [_int, _int, _vp, _vp, ctypes.c_float, _int, _vp, _vp, _vp]),
+    'pcc_auction_status': (_int, []),
+    'pcc_auction_test_inject_failure': (None, []),
     'pcc_auction_backward': (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

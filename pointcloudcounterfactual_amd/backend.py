@@ -219,6 +219,46 @@ def ChamferLossGrad(set_d: torch.Tensor, set_q: torch.Tensor, idx1: torch.Tensor
     return [grad1, grad2]
 
 
+def _batch_stride(g: torch.Tensor, b: int) -> tuple[torch.Tensor, int]:
+    """An upstream gradient [B] as (tensor, stride): one scalar expanded over the batch (what ``loss.sum().backward()``
+    hands down) is read in place through stride 0, no copy kernel."""
+    stride = g.stride(0) if g.dim() == 1 and b > 1 else 1
+    if stride not in (0, 1):
+        return g.contiguous(), 1
+    return g, stride
+
+
+def ChamferEMDGrad(set_d: torch.Tensor, set_q: torch.Tensor, idx1: torch.Tensor, idx2: torch.Tensor,
+                   grad_chamfer: torch.Tensor, mean: bool, emd_grad1: torch.Tensor, emd_grad2: torch.Tensor,
+                   grad_emd: torch.Tensor) -> list[torch.Tensor]:
+    """Backward of Chamfer + match_cost on the same clouds in ONE launch (extension, ``pcc_chamfer_emd_grad``):
+    ``ChamferLossGrad(grad_chamfer) + emd_grad * grad_emd[:, None, None]`` -> [grad1[B,N,3], grad2[B,M,3]]."""
+    b, n, m = _sizes(set_d, set_q)
+    grad1 = torch.empty((b, n, 3), dtype=torch.float32, device=set_d.device)
+    grad2 = torch.empty((b, m, 3), dtype=torch.float32, device=set_d.device)
+    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (idx1, 'idx1'), (idx2, 'idx2'), (emd_grad1, 'emd_grad1'),
+                    (emd_grad2, 'emd_grad2')):
+        _check_input(t, name)
+    for t, name in ((set_d, 'set_d'), (set_q, 'set_q'), (grad_chamfer, 'grad_chamfer'), (grad_emd, 'grad_emd'),
+                    (emd_grad1, 'emd_grad1'), (emd_grad2, 'emd_grad2')):
+        if t.device.type != 'cuda':
+            raise RuntimeError(f'{name} must be a CUDA tensor')
+        _f32(t, name)
+    _i32(idx1, 'idx1')
+    _i32(idx2, 'idx2')
+    if (idx1.numel() != b * n or idx2.numel() != b * m or grad_chamfer.numel() != b or grad_emd.numel() != b
+            or emd_grad1.numel() != b * n * 3 or emd_grad2.numel() != b * m * 3):
+        raise RuntimeError('ChamferEMDGrad: shapes do not match the clouds')
+    grad_chamfer, sc = _batch_stride(grad_chamfer, b)
+    grad_emd, se = _batch_stride(grad_emd, b)
+    with torch.cuda.device(set_d.device):
+        _lib.check(_L.pcc_chamfer_emd_grad(b, n, set_d.data_ptr(), m, set_q.data_ptr(), idx1.data_ptr(), idx2.data_ptr(),
+                                           grad_chamfer.data_ptr(), int(sc), int(mean), emd_grad1.data_ptr(),
+                                           emd_grad2.data_ptr(), grad_emd.data_ptr(), int(se), grad1.data_ptr(),
+                                           grad2.data_ptr(), _stream(set_d)), 'ChamferEMDGrad')
+    return [grad1, grad2]
+
+
 def NNDistanceGrad(set_d: torch.Tensor, set_q: torch.Tensor, idx1: torch.Tensor, idx2: torch.Tensor,
                    grad_dist1: torch.Tensor, grad_dist2: torch.Tensor) -> list[torch.Tensor]:
     """-> [grad1[B,N,3], grad2[B,M,3]]   (structural_loss.cpp:102-125)."""

@@ -2076,7 +2076,11 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
             (void)hipGetLastError();
             cap = hipStreamCaptureStatusNone;
         }
-        if (cap == hipStreamCaptureStatusNone) side = side_stream(0);
+        static const bool lanes_in_capture = [] {  // PCC_AM_CAPTURE_LANES=1: fork/join inside a capture (A/B measurements)
+            const char *e = std::getenv("PCC_AM_CAPTURE_LANES");
+            return e && e[0] == '1';
+        }();
+        if (cap == hipStreamCaptureStatusNone || lanes_in_capture) side = side_stream(0);
     }
     ForkJoin fj(st, side);
     ForkJoin fj2(st, fj.ok && want_lanes >= 3 ? side_stream(1) : nullptr);

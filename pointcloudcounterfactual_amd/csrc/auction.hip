@@ -8,6 +8,8 @@
 // Bid values follow emd_cuda.cu:145 literally: `3.0 - sqrtf(d2) - price` is DOUBLE arithmetic rounded once
 // to float; sqrtf is correctly rounded (-fno-fast-math).
 #include "pcc_common.hpp"
+
+#include <mutex>
 #include "pcc_emd.h"
 
 #include <algorithm>
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(1024) void auction_cluster_kernel(int n, int C, con
                                                                 const float *__restrict__ xyz2, float eps, int iters,
                                                                 float *__restrict__ dist, int *__restrict__ assignment,
                                                                 int *__restrict__ scratch, unsigned *__restrict__ sync,
-                                                                int smp0) {
+                                                                int smp0, unsigned *__restrict__ host_err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, T = 1024;
     const int smp = smp0 + (int)(blockIdx.x / C), c = (int)(blockIdx.x % C);
@@ -295,6 +297,8 @@ __global__ __launch_bounds__(1024) void auction_cluster_kernel(int n, int C, con
     }
     __syncthreads();
     const bool bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    // the failure also goes to a sticky word in host memory: the next pcc_auction_* call on this device reports it
+    if (bad && tid == 0 && host_err) __hip_atomic_store(host_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (int j = j0 + tid; j < j1; j += T) {  // CalcDist :216-225
         const int k = gld(&ass[j]);
         const bool valid = !bad && k >= 0 && k < n;
@@ -312,9 +316,52 @@ __global__ __launch_bounds__(256) void auction_bwd_kernel(size_t total, int n, c
     if (t >= total) return;
     const size_t smp = t / n;
     const int j2 = idx[t];
-    const float g = grad_dist[t] * 2;
+    // an assignment outside [0, n) (a point a failed forward left unassigned, -1) has no partner: zero gradient,
+    // never an out-of-range read
+    const bool valid = (unsigned)j2 < (unsigned)n;
+    const float g = valid ? grad_dist[t] * 2 : 0.f;
+    const size_t q = smp * n + (valid ? j2 : 0);
 #pragma unroll
-    for (int c = 0; c < 3; c++) grad1[t * 3 + c] = g * (xyz1[t * 3 + c] - xyz2[(smp * n + j2) * 3 + c]);
+    for (int c = 0; c < 3; c++) grad1[t * 3 + c] = valid ? g * (xyz1[t * 3 + c] - xyz2[q * 3 + c]) : 0.f;
+}
+
+// Per-device state of the cluster schedule: a sticky failure word in mapped host memory (set by a kernel whose sample
+// barrier timed out) and the event of the last cluster launch -- two cluster launches must never run at the same time
+// (each needs all of its workgroups resident; two of them on different streams could wait for each other forever),
+// so a launch on another stream first waits for the previous one.
+struct ClusterState {
+    unsigned *host_word = nullptr, *dev_word = nullptr;
+    hipEvent_t last = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool inject = false;
+};
+std::mutex g_cluster_mu;
+ClusterState *cluster_state() {
+    static ClusterState st[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    ClusterState &c = st[dev];
+    if (!c.host_word) {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        c.host_word = static_cast<unsigned *>(h);
+        c.dev_word = static_cast<unsigned *>(d);
+        *c.host_word = 0;
+        if (hipEventCreateWithFlags(&c.last, hipEventDisableTiming) != hipSuccess) c.last = nullptr;
+    }
+    return &c;
+}
+// nonzero if an earlier cluster launch on this device timed out (and clears the word)
+int take_cluster_failure() {
+    std::lock_guard<std::mutex> lk(g_cluster_mu);
+    ClusterState *c = cluster_state();
+    if (!c || !c->host_word) return 0;
+    const unsigned v = __atomic_exchange_n(c->host_word, 0u, __ATOMIC_RELAXED);
+    return v != 0;
 }
 
 }  // namespace
@@ -328,6 +375,9 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
     if (n > 8192) return pcc::invalid("auction: n > 8192 does not fit the LDS-resident state");
     if (b == 0) return PCC_OK;
     if (!xyz1 || !xyz2 || !dist || !assignment) return pcc::invalid("auction: null pointer");
+    if (take_cluster_failure())
+        return pcc::invalid("auction: an earlier launch on this device did not complete (a sample barrier timed out: its "
+                            "outputs were poisoned with NaN / -1); this call was not started");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // ---- cluster schedule: C workgroups per sample when they can all be resident at once ----
     {
@@ -368,11 +418,30 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
             int *scratch = reinterpret_cast<int *>(ws);
             unsigned *sync = reinterpret_cast<unsigned *>(ws + (size_t)b * 4 * n * 4);
             (void)hipMemsetAsync(sync, 0, sync_words * 4, st);
+            unsigned *host_err = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(g_cluster_mu);
+                ClusterState *cs = cluster_state();
+                if (cs) {
+                    host_err = cs->dev_word;
+                    // never two cluster launches at once: a launch on another stream waits for the previous one
+                    if (cs->last && cs->last_stream && cs->last_stream != st) (void)hipStreamWaitEvent(st, cs->last, 0);
+                    if (cs->inject) {  // test hook: start with the error word raised
+                        (void)hipMemsetAsync(sync, 1, 1, st);
+                        cs->inject = false;
+                    }
+                }
+            }
             for (int s0 = 0; s0 < b; s0 += group) {
                 const int gb = std::min(group, b - s0);
                 pcc::ProfScope prof("auction_cluster_kernel", st);
                 hipLaunchKernelGGL(auction_cluster_kernel, dim3((unsigned)(gb * C)), dim3(1024), lds, st, n, C, xyz1, xyz2, eps,
-                                   iters, dist, assignment, scratch, sync, s0);
+                                   iters, dist, assignment, scratch, sync, s0, host_err);
+            }
+            {
+                std::lock_guard<std::mutex> lk(g_cluster_mu);
+                ClusterState *cs = cluster_state();
+                if (cs && cs->last && hipEventRecord(cs->last, st) == hipSuccess) cs->last_stream = st;
             }
             (void)hipFreeAsync(ws, st);
             return pcc::check_launch("auction_forward(cluster)");
@@ -401,9 +470,21 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
     return pcc::check_launch("auction_forward");
 }
 
+int pcc_auction_status(void) {
+    return take_cluster_failure() ? 1 : 0;
+}
+
+void pcc_auction_test_inject_failure(void) {
+    std::lock_guard<std::mutex> lk(g_cluster_mu);
+    if (ClusterState *cs = cluster_state()) cs->inject = true;
+}
+
 int pcc_auction_backward(int b, int n, const float *xyz1, const float *xyz2, const float *grad_dist,
                          const int *assignment, float *grad_xyz1, pcc_stream_t stream) {
     pcc::clear_error();
+    if (take_cluster_failure())
+        return pcc::invalid("auction_backward: the forward launch on this device did not complete (a sample barrier timed "
+                            "out: dist was poisoned with NaN, unassigned points are -1)");
     if (b < 0 || n < 0) return pcc::invalid("auction_backward: bad size");
     if (b == 0 || n == 0) return PCC_OK;
     if (!xyz1 || !xyz2 || !grad_dist || !assignment || !grad_xyz1) return pcc::invalid("auction_backward: null pointer");

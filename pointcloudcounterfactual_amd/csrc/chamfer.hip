@@ -191,7 +191,10 @@ __global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *_
                                                             const float *__restrict__ gd2,
                                                             const int *__restrict__ idx2,
                                                             float *__restrict__ grad1, float *__restrict__ grad2,
-                                                            int P, const float *__restrict__ gloss, int mean, int gloss_stride) {
+                                                            int P, const float *__restrict__ gloss, int mean, int gloss_stride,
+                                                            const float *__restrict__ add1,
+                                                            const float *__restrict__ add2,
+                                                            const float *__restrict__ add_scale, int add_stride) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
     const int smp = blockIdx.y, p = blockIdx.x;
     const int tid = threadIdx.x, T = 256;
@@ -243,6 +246,17 @@ __global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *_
     __syncthreads();
     float *o1 = grad1 + ((size_t)smp * n + j0) * 3;
     float *o2 = grad2 + ((size_t)smp * m + k0) * 3;
+    if (add1) {
+        // a second loss on the same clouds (the reference's ChamferEMD reconstruction loss, metrics_and_losses.py:70-79):
+        // its gradients, scaled by its upstream gradient, join here -- rounded product, then rounded sum, i.e. the bits
+        // autograd's `grad * scale` followed by gradient accumulation would give
+        const float as = add_scale ? add_scale[(size_t)smp * add_stride] : 1.0f;
+        const float *a1 = add1 + ((size_t)smp * n + j0) * 3;
+        const float *a2 = add2 + ((size_t)smp * m + k0) * 3;
+        for (int i = tid; i < (j1 - j0) * 3; i += T) o1[i] = acc1[i] + a1[i] * as;
+        for (int i = tid; i < (k1 - k0) * 3; i += T) o2[i] = acc2[i] + a2[i] * as;
+        return;
+    }
     for (int i = tid; i < (j1 - j0) * 3; i += T) o1[i] = acc1[i];
     for (int i = tid; i < (k1 - k0) * 3; i += T) o2[i] = acc2[i];
 }
@@ -273,7 +287,8 @@ __global__ __launch_bounds__(256) void chamfer_reduce_kernel(int n, int m, const
 
 int launch_bwd(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad_dist1, const int *idx1,
                const float *grad_dist2, const int *idx2, const float *gloss, int mean, int gloss_stride,
-               float *grad_xyz1, float *grad_xyz2, hipStream_t st) {
+               float *grad_xyz1, float *grad_xyz2, hipStream_t st, const float *add1 = nullptr,
+               const float *add2 = nullptr, const float *add_scale = nullptr, int add_stride = 1) {
     // P destination ranges per sample: ~512 workgroups on the chip, each range pair <= 48 KiB of LDS.
     long long P = std::max<long long>(1, pcc::ceil_div(512, b));
     P = std::min<long long>(P, std::max(1, std::min(n, m) / 64));
@@ -284,7 +299,8 @@ int launch_bwd(int b, int n, const float *xyz1, int m, const float *xyz2, const 
     {
         pcc::ProfScope prof("nn_bwd_range_kernel", st);
         hipLaunchKernelGGL(nn_bwd_range_kernel, dim3((unsigned)P, (unsigned)b), dim3(256), lds, st, n, xyz1, m, xyz2,
-                           grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, (int)P, gloss, mean, gloss_stride);
+                           grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, (int)P, gloss, mean, gloss_stride,
+                           add1, add2, add_scale, add_stride);
     }
     return pcc::check_launch("nndistancegrad");
 }
@@ -375,6 +391,22 @@ int pcc_chamfer_loss_grad(int b, int n, const float *xyz1, int m, const float *x
     if (grad_loss_stride != 0 && grad_loss_stride != 1) return pcc::invalid("chamfer_loss_grad: grad_loss stride must be 0 or 1");
     return launch_bwd(b, n, xyz1, m, xyz2, nullptr, idx1, nullptr, idx2, grad_loss, mean, grad_loss_stride, grad_xyz1, grad_xyz2,
                       static_cast<hipStream_t>(stream));
+}
+
+int pcc_chamfer_emd_grad(int b, int n, const float *xyz1, int m, const float *xyz2, const int *idx1, const int *idx2,
+                         const float *grad_chamfer, int grad_chamfer_stride, int mean, const float *emd_grad1,
+                         const float *emd_grad2, const float *grad_emd, int grad_emd_stride, float *grad_xyz1,
+                         float *grad_xyz2, pcc_stream_t stream) {
+    pcc::clear_error();
+    if (b < 0 || n < 0 || m < 0) return pcc::invalid("chamfer_emd_grad: negative size");
+    if (b == 0 || (n == 0 && m == 0)) return PCC_OK;
+    if (n == 0 || m == 0) return pcc::invalid("chamfer_emd_grad: one cloud is empty");
+    if (!xyz1 || !xyz2 || !idx1 || !idx2 || !grad_chamfer || !emd_grad1 || !emd_grad2 || !grad_xyz1 || !grad_xyz2)
+        return pcc::invalid("chamfer_emd_grad: null pointer");
+    if ((grad_chamfer_stride != 0 && grad_chamfer_stride != 1) || (grad_emd_stride != 0 && grad_emd_stride != 1))
+        return pcc::invalid("chamfer_emd_grad: gradient strides must be 0 or 1");
+    return launch_bwd(b, n, xyz1, m, xyz2, nullptr, idx1, nullptr, idx2, grad_chamfer, mean, grad_chamfer_stride, grad_xyz1,
+                      grad_xyz2, static_cast<hipStream_t>(stream), emd_grad1, emd_grad2, grad_emd, grad_emd_stride);
 }
 
 void nndistancegrad(int b, int n, const float *xyz1, int m, const float *xyz2, const float *grad_dist1,

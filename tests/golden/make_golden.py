@@ -71,6 +71,28 @@ def make_reference_fixture():
     xf = torch.rand(2, 3, 200, generator=g)
     out['filt_x'] = xf.numpy()
     out['filt_out'] = ref.graph_filtering(xf.clone(), k=4).numpy()
+    # get_local_covariance (:97-103) on the kNN the reference computes itself
+    xc = torch.randn(2, 3, 150, generator=g)
+    out['cov_x'] = xc.numpy()
+    out['cov_k'] = np.int64(16)
+    out['cov_out'] = ref.get_local_covariance(xc.clone(), indices=torch.empty(0), k=16).numpy()
+    # BASELINE configs[0] at its exact shape (ModelNet40-like N=1024, B=4, Chamfer only, CPU reference path):
+    # torch_square_distance (:43-50) + the torch_chamfer body (metrics_and_losses.py:46-47) and its autograd
+    # gradients.  The [4,1024,1024] matrix itself (16 MiB) is not stored: its row / column minima and argmins are.
+    from tests.util import pair
+
+    a, c = pair(1234 + 1, 4, 1024, 1024, 'recon')
+    t1 = torch.from_numpy(a).requires_grad_(True)
+    t2 = torch.from_numpy(c).requires_grad_(True)
+    d = ref.torch_square_distance(t1, t2)
+    m1, m2 = torch.min(d, dim=-1), torch.min(d, dim=-2)
+    loss = m1[0].sum(1) + m2[0].sum(1)
+    loss.sum().backward()
+    out['cfg1_t1'], out['cfg1_t2'] = a, c
+    out['cfg1_dist1'], out['cfg1_idx1'] = m1[0].detach().numpy(), m1[1].numpy().astype(np.int32)
+    out['cfg1_dist2'], out['cfg1_idx2'] = m2[0].detach().numpy(), m2[1].numpy().astype(np.int32)
+    out['cfg1_chamfer_sum'] = loss.detach().numpy()
+    out['cfg1_grad1'], out['cfg1_grad2'] = t1.grad.numpy(), t2.grad.numpy()
     np.savez_compressed(os.path.join(HERE, 'ref_neighbour_ops.npz'), **out)
     print('wrote ref_neighbour_ops.npz', {k: v.shape for k, v in out.items()})
 

@@ -143,3 +143,62 @@ def test_emd_module_input_checks():
         emdModule()(torch.zeros(1, 100, 3), torch.zeros(1, 100, 3), 0.005, 10)
     with pytest.raises(ValueError, match='same number of points'):
         emdModule()(torch.zeros(1, 1024, 3), torch.zeros(1, 2048, 3), 0.005, 10)
+
+
+@pytest.mark.gpu
+def test_auction_failure_is_reported_not_silent(cuda):
+    """A cluster launch whose sample barrier fails (here: injected through the test hook, which raises the kernel's
+    error word before the launch) poisons its outputs AND surfaces as an error: the next call on the device raises
+    instead of returning rc 0, the backward pass of a poisoned assignment (-1) reads nothing out of range and gives a
+    zero gradient, and the device recovers afterwards."""
+    from emd import emd_backend
+    from pointcloudcounterfactual_amd import _lib
+
+    a, c = _clouds(7, 4, 2048)
+    t1, t2 = torch.from_numpy(a).to(cuda), torch.from_numpy(c).to(cuda)
+    dist = torch.zeros(4, 2048, device=cuda)
+    ass = torch.zeros(4, 2048, device=cuda, dtype=torch.int32)
+    _lib.lib.pcc_auction_test_inject_failure()
+    assert emd_backend.forward(t1, t2, dist, ass, eps=0.005, iters=20) == 1  # the launch itself is asynchronous
+    torch.cuda.synchronize()
+    assert torch.isnan(dist).all() and (ass == -1).all()
+    grad = torch.full((4, 2048, 3), 7.0, device=cuda)
+    with pytest.raises(RuntimeError, match='did not complete'):
+        emd_backend.backward(t1, t2, grad, torch.ones(4, 2048, device=cuda), ass)
+    # the word is cleared by the report: the same backward now runs and an unassigned point gets a zero gradient
+    emd_backend.backward(t1, t2, grad, torch.ones(4, 2048, device=cuda), ass)
+    torch.cuda.synchronize()
+    assert float(grad.abs().max()) == 0.0
+    assert _lib.lib.pcc_auction_status() == 0
+    emd_backend.forward(t1, t2, dist, ass, eps=0.005, iters=20)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dist).all() and (ass >= 0).all()
+    # and the other way round: a failed forward followed by a forward
+    _lib.lib.pcc_auction_test_inject_failure()
+    emd_backend.forward(t1, t2, dist, ass, eps=0.005, iters=20)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='did not complete'):
+        emd_backend.forward(t1, t2, dist, ass, eps=0.005, iters=20)
+    emd_backend.forward(t1, t2, dist, ass, eps=0.005, iters=20)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dist).all()
+
+
+@pytest.mark.gpu
+def test_auction_cluster_launches_on_two_streams(cuda):
+    """Two cluster launches enqueued on different streams are ordered by the library (each needs all its workgroups
+    resident): both finish with the bits of a launch on its own."""
+    from emd import emdModule
+
+    a, c = _clouds(9, 8, 2048)
+    t1, t2 = torch.from_numpy(a).to(cuda), torch.from_numpy(c).to(cuda)
+    ref_d, ref_a = emdModule()(t1, t2, 0.005, 30)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for st in (s1, s2, s1, s2):
+        with torch.cuda.stream(st):
+            outs.append(emdModule()(t1, t2, 0.005, 30))
+    torch.cuda.synchronize()
+    for d, asg in outs:
+        assert torch.equal(d, ref_d) and torch.equal(asg, ref_a)

@@ -105,34 +105,37 @@ def test_approxmatch_vs_oracle(cuda, oracle_mod, b, n, m, kind):
 
     a, c = pair(300 + n + m, b, n, m, kind)
     match, temp = backend.ApproxMatch(_dev(a, cuda), _dev(c, cuda))
-    om, ot = oracle_mod.approxmatch(a, c)
-    oracle_mod.set_exp_mode(1)
-    om_alt, _ = oracle_mod.approxmatch(a, c)
-    oracle_mod.set_exp_mode(0)
-    om64, _ = oracle_mod.approxmatch_f64(a, c)
+    om64, ot64 = oracle_mod.approxmatch_f64(a, c)
     got = match.cpu().numpy()
-    # Element-wise the f32 recurrence is ill-conditioned (remain* are clamped differences that feed
-    # ratios): two correctly rounded f32 evaluations that differ only in how exp is arranged
-    # (oracle exp_mode 0 vs 1) already differ by ~3e-4 at N=2048, and either sits ~4e-4 from the float64
-    # recurrence.  Bar for elements: within 10x of that intrinsic f32 spread.  The well-conditioned
-    # quantities (row / column masses, cost) are held to 1e-5.
-    spread = max(np.abs(om - om64).max(), np.abs(om - om_alt).max())
+    gtemp = temp.cpu().numpy()[:, : n + m]
+    # Element-wise the f32 recurrence is ill-conditioned (remain* are clamped differences that feed ratios): LEGITIMATE
+    # float32 evaluations of the reference's own formulas -- the oracle with exp taken as libm expf, as exp2 of the
+    # exactly scaled argument, as CUDA's documented __expf argument path, and with ex2.approx's permitted 2 ulp
+    # (oracle exp modes 0-3) -- sit up to 7e-4 from the float64 recurrence and from each other at N=2048.  Bars
+    # (measured: tools/parity_report.py, gpurun_out/parity_report.jsonl): elements, per-point masses and remainders
+    # within 3x that spread (floors 5e-5 / 1e-5 where the spread itself is at rounding level); total mass and
+    # cost -- the well-conditioned quantities -- 1e-5 relative, flat (north_star).
+    spread = mspread1 = mspread2 = rspread = 0.0
+    try:
+        for mode in (0, 1, 2, 3):
+            oracle_mod.set_exp_mode(mode)
+            om, ot = oracle_mod.approxmatch(a, c)
+            spread = max(spread, np.abs(om - om64).max())
+            mspread1 = max(mspread1, np.abs(om.sum(1) - om64.sum(1)).max())
+            mspread2 = max(mspread2, np.abs(om.sum(2) - om64.sum(2)).max())
+            rspread = max(rspread, np.abs(ot[:, : n + m] - ot64[:, : n + m]).max())
+    finally:
+        oracle_mod.set_exp_mode(0)
     err_ours = np.abs(got - om64).max()
-    assert err_ours <= max(10 * spread, 1e-5), (err_ours, spread)
-    # per-point masses: same yardstick (when capacity is scarce, e.g. n=257 vs m=130 with multiR=1, which
-    # points win the capacity is itself ill-conditioned); total mass per sample to 1e-5 relative.
-    for ax in (1, 2):
-        mspread = max(np.abs(om.sum(ax) - om64.sum(ax)).max(), np.abs(om.sum(ax) - om_alt.sum(ax)).max())
-        assert np.abs(got.sum(ax) - om64.sum(ax)).max() <= max(10 * mspread, 1e-5)
+    assert err_ours <= max(3 * spread, 5e-5), (err_ours, spread)
+    assert np.abs(got.sum(1) - om64.sum(1)).max() <= max(3 * mspread1, 1e-5)
+    assert np.abs(got.sum(2) - om64.sum(2)).max() <= max(3 * mspread2, 1e-5)
     np.testing.assert_allclose(got.sum((1, 2)), om64.sum((1, 2)), rtol=1e-5)
-    rem_spread = max(np.abs(ot[:, : n + m] - oracle_mod.approxmatch_f64(a, c)[1][:, : n + m]).max(), 1e-6)
-    assert np.abs(temp.cpu().numpy()[:, : n + m] - ot[:, : n + m]).max() <= 20 * rem_spread  # remainL | remainR
-    # cost: 1e-5 relative against the float64 recurrence's cost (north_star tolerance)
+    assert np.abs(gtemp - ot64[:, : n + m]).max() <= max(3 * rspread, 1e-5), rspread  # remainL | remainR
+    # cost: 1e-5 relative against the float64 recurrence's cost (north_star tolerance), no widening
     cost = backend.MatchCost(_dev(a, cuda), _dev(c, cuda), match).cpu().numpy()
     oc64 = oracle_mod.matchcost_f64(a, c, om64)
-    oc32 = oracle_mod.matchcost(a, c, om)
-    tol = max(1e-5, 4 * np.abs(oc32 - oc64).max() / max(np.abs(oc64).max(), 1e-30))
-    np.testing.assert_allclose(cost, oc64, rtol=tol, atol=1e-7)
+    np.testing.assert_allclose(cost, oc64, rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize('b,n,m', [(2, 3, 5), (2, 257, 130), (2, 1024, 1024), (1, 100, 2100)])
@@ -349,24 +352,29 @@ def test_implicit_match_cost_equals_materialised(cuda, b, n, m, kind):
 
 @pytest.mark.parametrize('b,n,m', [(2, 3, 5), (2, 257, 130), (2, 1024, 1024)])
 def test_implicit_match_cost_vs_oracle(cuda, oracle_mod, b, n, m):
-    """pcc_match_cost against the float64 recurrence of the oracle: cost to 1e-5 (north_star), gradients within the
-    oracle's own f32-vs-f64 spread (the match elements are ill-conditioned, see test_approxmatch_vs_oracle)."""
+    """pcc_match_cost against the float64 recurrence of the oracle: cost to a flat 1e-5 (north_star), gradients within
+    3x the spread of the oracle's own legitimate float32 evaluations (the match elements are ill-conditioned, see
+    test_approxmatch_vs_oracle; floor 5e-5 of the largest component where that spread is at rounding level)."""
     from pointcloudcounterfactual_amd import backend
 
     a, c = pair(300 + n + m, b, n, m)
     cost, g1, g2 = backend.MatchCostImplicit(_dev(a, cuda), _dev(c, cuda), True)
-    om, _ = oracle_mod.approxmatch(a, c)
     om64, _ = oracle_mod.approxmatch_f64(a, c)
     oc64 = oracle_mod.matchcost_f64(a, c, om64)
-    oc32 = oracle_mod.matchcost(a, c, om)
-    tol = max(1e-5, 4 * np.abs(oc32 - oc64).max() / max(np.abs(oc64).max(), 1e-30))
-    np.testing.assert_allclose(cost.cpu().numpy(), oc64, rtol=tol, atol=1e-7)
+    np.testing.assert_allclose(cost.cpu().numpy(), oc64, rtol=1e-5, atol=1e-7)
     h1, h2 = oracle_mod.matchcostgrad_f64(a, c, om64)
-    f1, f2 = oracle_mod.matchcostgrad(a, c, om)
     scale = max(np.abs(h1).max(), np.abs(h2).max())
-    spread = max(np.abs(f1 - h1).max(), np.abs(f2 - h2).max())
-    assert np.abs(g1.cpu().numpy() - h1).max() <= max(10 * spread, 1e-5 * scale)
-    assert np.abs(g2.cpu().numpy() - h2).max() <= max(10 * spread, 1e-5 * scale)
+    spread = 0.0
+    try:
+        for mode in (0, 1, 2, 3):  # legitimate float32 evaluations of the reference's formulas (oracle exp modes)
+            oracle_mod.set_exp_mode(mode)
+            om, _ = oracle_mod.approxmatch(a, c)
+            f1, f2 = oracle_mod.matchcostgrad(a, c, om)
+            spread = max(spread, np.abs(f1 - h1).max(), np.abs(f2 - h2).max())
+    finally:
+        oracle_mod.set_exp_mode(0)
+    assert np.abs(g1.cpu().numpy() - h1).max() <= max(3 * spread, 5e-5 * scale)
+    assert np.abs(g2.cpu().numpy() - h2).max() <= max(3 * spread, 5e-5 * scale)
 
 
 def test_implicit_match_cost_edge_cases(cuda):
@@ -514,11 +522,8 @@ def test_random_shape_sweep(cuda, oracle_mod):
         g1, g2 = backend.MatchCostGrad(t1, t2, match)
         cost_i, h1, h2 = backend.MatchCostImplicit(t1, t2, True)
         om64, _ = oracle_mod.approxmatch_f64(a, c)
-        om32, _ = oracle_mod.approxmatch(a, c)
         oc64 = oracle_mod.matchcost_f64(a, c, om64)
-        oc32 = oracle_mod.matchcost(a, c, om32)
-        tol = max(1e-5, 4 * np.abs(oc32 - oc64).max() / max(np.abs(oc64).max(), 1e-30))
-        np.testing.assert_allclose(cost.cpu().numpy(), oc64, rtol=tol, atol=1e-6, err_msg=str((b, n, m, kind)))
+        np.testing.assert_allclose(cost.cpu().numpy(), oc64, rtol=1e-5, atol=1e-6, err_msg=str((b, n, m, kind)))
         np.testing.assert_allclose(cost_i.cpu().numpy(), cost.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=str((b, n, m, kind)))
         scale = max(float(g1.abs().max()), float(g2.abs().max()), 1e-30)
         np.testing.assert_allclose(h1.cpu().numpy(), g1.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale, err_msg=str((b, n, m)))
@@ -539,3 +544,36 @@ def test_lanes_with_odd_batch_and_unequal_clouds(cuda):
         assert torch.equal(cs, cost[s:s + 1]) and torch.equal(h1, g1[s:s + 1]) and torch.equal(h2, g2[s:s + 1]), s
         ms, _ts, mc = backend.ApproxMatchCost(t1[s:s + 1].contiguous(), t2[s:s + 1].contiguous())
         assert torch.equal(mc, mcost[s:s + 1]) and torch.equal(ms, match[s:s + 1]), s
+
+
+@pytest.mark.parametrize('reduction', ['mean', 'sum'])
+@pytest.mark.parametrize('b,n,m', [(2, 3, 5), (3, 257, 130), (8, 2048, 2048)])
+def test_chamfer_emd_node_equals_separate_losses(cuda, b, n, m, reduction):
+    """chamfer_emd() (one autograd node: nearest-neighbour search on a side stream in the shadow of the approximate-EMD
+    launch chain, one backward launch for the total gradient) carries the bits of chamfer() and match_cost() called one
+    after the other, forward and backward, with per-sample upstream weights and with the expanded scalar that
+    ``loss.sum().backward()`` hands down."""
+    from pointcloudcounterfactual_amd.losses import chamfer, chamfer_emd, match_cost
+
+    a, c = pair(700 + n, b, n, m)
+    for weights in (None, torch.linspace(-1.0, 2.0, b, device=cuda)):
+        t1 = _dev(a, cuda).requires_grad_(True)
+        t2 = _dev(c, cuda).requires_grad_(True)
+        lc, le = chamfer_emd(t1, t2, reduction)
+        total = lc + 0.5 * le
+        (total.sum() if weights is None else (total * weights).sum()).backward()
+        u1 = _dev(a, cuda).requires_grad_(True)
+        u2 = _dev(c, cuda).requires_grad_(True)
+        rc, re = chamfer(u1, u2, reduction), match_cost(u1, u2)
+        ref = rc + 0.5 * re
+        (ref.sum() if weights is None else (ref * weights).sum()).backward()
+        assert torch.equal(lc, rc) and torch.equal(le, re)
+        assert torch.equal(t1.grad, u1.grad) and torch.equal(t2.grad, u2.grad)
+    # only one input requires a gradient / none does
+    t1 = _dev(a, cuda).requires_grad_(True)
+    lc, le = chamfer_emd(t1, _dev(c, cuda), reduction)
+    (lc + le).sum().backward()
+    assert t1.grad is not None and torch.isfinite(t1.grad).all()
+    with torch.no_grad():
+        lc2, le2 = chamfer_emd(_dev(a, cuda), _dev(c, cuda), reduction)
+    assert torch.equal(lc2, lc) and torch.equal(le2, le)

@@ -87,3 +87,14 @@ def test_cpu_graph_filtering_reproduces_reference():
 
     out = ops.graph_filtering(torch.from_numpy(GOLD['filt_x']).clone(), k=4)
     torch.testing.assert_close(out, torch.from_numpy(GOLD['filt_out']), rtol=0, atol=0)
+
+
+def test_cpu_get_local_covariance_reproduces_reference():
+    """get_local_covariance (reference neighbour_ops.py:97-103) on CPU tensors against the reference's own output
+    (the reference subtracts the neighbourhood mean in place; ours out of place: same values)."""
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    x = torch.from_numpy(GOLD['cov_x']).clone()
+    out = ops.get_local_covariance(x, torch.empty(0), int(GOLD['cov_k']))
+    assert torch.equal(x, torch.from_numpy(GOLD['cov_x']))  # the input is not modified
+    torch.testing.assert_close(out, torch.from_numpy(GOLD['cov_out']), rtol=0, atol=0)

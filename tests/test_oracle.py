@@ -187,3 +187,37 @@ def test_config1_cpu_chamfer_plumbing(oracle_mod):
     np.testing.assert_allclose(loss.detach().numpy(), d1.sum(1) + d2.sum(1), rtol=2e-5)
     g1, _ = oracle_mod.nndistancegrad(a, c, i1, i2, np.ones_like(d1), np.ones_like(d2))
     np.testing.assert_allclose(t1.grad.numpy(), g1, rtol=1e-3, atol=2e-5)
+
+
+def test_oracle_nndistance_pinned_by_reference_generated_vectors(oracle_mod):
+    """The one piece of this path the reference can execute without CUDA: torch_square_distance
+    (src/utils/neighbour_ops.py:43-50) + the torch_chamfer body (metrics_and_losses.py:46-47) and their autograd
+    gradients, captured by tests/golden/make_golden.py from the imported reference at BASELINE configs[0]'s exact
+    shape (B=4, N=1024) and at a small ragged shape.  The oracle's nearest neighbours (and therefore the HIP kernel's,
+    which are bit-exact against the oracle) must be the reference's: equal indices outside float64-certified near
+    ties, distances within 1e-5 relative + the reference's own cancellation floor (8 ulp of |p|^2 + |q|^2), loss
+    1e-5, gradients 1e-5 of the largest component."""
+    z = np.load(os.path.join(GOLD, 'ref_neighbour_ops.npz'), allow_pickle=False)
+    cases = {
+        'cfg1': (z['cfg1_t1'], z['cfg1_t2'], z['cfg1_dist1'], z['cfg1_idx1'], z['cfg1_dist2'], z['cfg1_idx2'],
+                 z['cfg1_chamfer_sum']),
+        'cd': (z['cd_t1'], z['cd_t2'], z['cd_dist'].min(2), z['cd_dist'].argmin(2), z['cd_dist'].min(1),
+               z['cd_dist'].argmin(1), z['cd_chamfer_sum']),
+    }
+    for tag, (a, c, rd1, ri1, rd2, ri2, rloss) in cases.items():
+        floor = 8 * np.finfo(np.float32).eps * float((a ** 2).sum(-1).max() + (c ** 2).sum(-1).max())
+        d1, i1, d2, i2 = oracle_mod.nndistance(a, c)
+        for (p, q, io, ir) in ((a, c, i1, ri1), (c, a, i2, ri2)):
+            for b, j in np.argwhere(io != ir):
+                do = ((p[b, j].astype(np.float64) - q[b, io[b, j]]) ** 2).sum()
+                dr = ((p[b, j].astype(np.float64) - q[b, ir[b, j]]) ** 2).sum()
+                assert abs(do - dr) <= floor, (tag, b, j)
+        np.testing.assert_allclose(d1, rd1, rtol=1e-5, atol=floor)
+        np.testing.assert_allclose(d2, rd2, rtol=1e-5, atol=floor)
+        loss = d1.astype(np.float64).sum(1) + d2.astype(np.float64).sum(1)
+        np.testing.assert_allclose(loss, rloss, rtol=1e-5)
+        if tag == 'cfg1' and np.array_equal(i1, ri1) and np.array_equal(i2, ri2):
+            g1, g2 = oracle_mod.nndistancegrad(a, c, i1, i2, np.ones_like(d1), np.ones_like(d2))
+            scale = max(np.abs(z['cfg1_grad1']).max(), np.abs(z['cfg1_grad2']).max())
+            np.testing.assert_allclose(g1, z['cfg1_grad1'], rtol=1e-5, atol=1e-5 * scale)
+            np.testing.assert_allclose(g2, z['cfg1_grad2'], rtol=1e-5, atol=1e-5 * scale)

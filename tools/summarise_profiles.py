@@ -24,10 +24,12 @@ os.makedirs(P, exist_ok=True)
 
 
 def short(name: str) -> str:
-    m = re.search(r'(am_\w+|nn_\w+|reduce_\w+|knn_\w+|graph_\w+|auction_\w+|emd_\w+)(<[^>(]*>)?', name)
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '', 1) if name.startswith('void ') else name.replace('(anonymous namespace)::', '')
+    m = re.search(r'(am_\w+|nn_\w+|pair_\w+|chamfer_\w+|reduce_\w+|knn_\w+|gather_\w+|scatter_\w+|global_\w+|graph_\w+|auction_\w+|emd_\w+)(<[^>(]*>)?', name)
     if m:
         return m.group(0)
-    return re.sub(r'\(.*', '', name)[:80]
+    return re.sub(r'\(.*', '', name)[:80] or 'unnamed'
+
 
 
 def one(pattern: str) -> str | None:
@@ -47,7 +49,7 @@ if stats:
     print('wrote', f'profiles/{out_tag}_kernel_stats.csv')
 
 pmc: dict[str, dict[str, list[float]]] = defaultdict(lambda: defaultdict(list))
-for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
+for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_trans'):
     f = one(f'{tag}_{sub}/*/*counter_collection.csv')
     if not f:
         continue
@@ -67,11 +69,13 @@ if pmc:
         if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
             key = re.sub(r'<.*', '', k)
             n = len(d['FETCH_SIZE'])  # dispatches of this instantiation: the family average is dispatch-weighted
-            e = summary.setdefault(key, {'fetch_kib_raw': 0.0, 'write_kib': 0.0, 'valu_insts': 0.0, 'dispatches': 0})
+            e = summary.setdefault(key, {'fetch_kib_raw': 0.0, 'write_kib': 0.0, 'valu_insts': 0.0, 'trans_insts': 0.0, 'dispatches': 0})
             e['fetch_kib_raw'] += sum(d['FETCH_SIZE'])
             e['write_kib'] += sum(d['WRITE_SIZE']) * n / max(len(d['WRITE_SIZE']), 1)
             if d.get('SQ_INSTS_VALU'):
                 e['valu_insts'] += sum(d['SQ_INSTS_VALU']) * n / len(d['SQ_INSTS_VALU'])
+            if d.get('SQ_INSTS_VALU_TRANS_F32'):
+                e['trans_insts'] += sum(d['SQ_INSTS_VALU_TRANS_F32']) * n / len(d['SQ_INSTS_VALU_TRANS_F32'])
             e['dispatches'] += n
     for key, v in summary.items():
         n = v['dispatches']
@@ -79,6 +83,8 @@ if pmc:
         v['write_kib'] /= n
         # wave-level VALU instructions per launch (SQ_INSTS_VALU, summed over the chip): x64 = lane operations
         v['valu_insts_per_launch'] = v.pop('valu_insts') / n
+        t = v.pop('trans_insts') / n
+        v['trans_insts_per_launch'] = t if t > 0 else None  # v_exp_f32 / v_rsq_f32 / v_sqrt_f32 (4 issue slots each)
         # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> x2 (upper bound for
         # narrow accesses); WRITE_SIZE is exact.  Units are KiB.
         v['hbm_bytes_per_launch'] = (2.0 * v['fetch_kib_raw'] + v['write_kib']) * 1024.0
