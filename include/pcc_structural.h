@@ -86,6 +86,13 @@ int pcc_chamfer_loss_grad(int b, int n, const float *xyz1, int m, const float *x
                           const float *grad_loss, int grad_loss_stride, int mean, float *grad_xyz1, float *grad_xyz2,
                           pcc_stream_t stream);
 
+/* Forward of the reference's ChamferEMD reconstruction loss (src/train/metrics_and_losses.py:70-79: Chamfer and
+ * match_cost on the same pair of clouds) in one call: pcc_chamfer_loss + pcc_match_cost, same outputs, same bits.
+ * emd_grad1 / emd_grad2: both or neither (NULL: cost only). */
+int pcc_chamfer_emd(int b, int n, const float *xyz1, int m, const float *xyz2, int mean, float *chamfer_loss,
+                    float *dist1, int *idx1, float *dist2, int *idx2, float *emd_cost, float *emd_grad1,
+                    float *emd_grad2, pcc_stream_t stream);
+
 /* Backward of the reference's ChamferEMD reconstruction loss (src/train/metrics_and_losses.py:70-79: Chamfer and
  * match_cost on the same pair of clouds) in one launch: pcc_chamfer_loss_grad of grad_chamfer[b] plus the unscaled
  * match_cost gradients emd_grad1[b,n,3] / emd_grad2[b,m,3] (as pcc_match_cost returns them) times grad_emd[b]

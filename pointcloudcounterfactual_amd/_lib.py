@@ -36,6 +36,7 @@ ABI: dict[str, tuple[object, list[object]]] = {
     'pcc_nndistancegrad': (_int, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcc_chamfer_loss': (_int, [_int, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcc_chamfer_loss_grad': (_int, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp]),
+    'pcc_chamfer_emd': (_int, [_int, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'pcc_chamfer_emd_grad': (_int, [_int, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _int, _vp, _vp, _vp]),
     'approxmatch': (None, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     'pcc_approxmatch': (_int, [_int, _int, _int, _vp, _vp, _vp, _vp, _vp]),

@@ -219,6 +219,37 @@ def ChamferLossGrad(set_d: torch.Tensor, set_q: torch.Tensor, idx1: torch.Tensor
     return [grad1, grad2]
 
 
+def ChamferEMD(set_d: torch.Tensor, set_q: torch.Tensor, mean: bool, with_grad: bool) -> list[torch.Tensor]:
+    """``ChamferLoss`` and ``MatchCostImplicit`` on the same pair of clouds in ONE call (extension, ``pcc_chamfer_emd``;
+    the reference's ChamferEMD loss, metrics_and_losses.py:70-79) -> [chamfer[B], idx1, idx2, emd[B]] (+ [emd_grad1,
+    emd_grad2] ``with_grad``).  Same bits as the two calls; the nearest-neighbour search is scheduled by the library on
+    an internal stream in the shadow of the approximate EMD's late passes."""
+    b, n, m = _sizes(set_d, set_q)
+    dev = set_d.device
+    _check_input(set_d, 'set_d')
+    _check_input(set_q, 'set_q')
+    _f32(set_d, 'set_d')
+    _f32(set_q, 'set_q')
+    loss = torch.empty((b,), dtype=torch.float32, device=dev)
+    idx1 = torch.empty((b, n), dtype=torch.int32, device=dev)
+    idx2 = torch.empty((b, m), dtype=torch.int32, device=dev)
+    cost = torch.empty((b,), dtype=torch.float32, device=dev)
+    out = [loss, idx1, idx2, cost]
+    g1 = g2 = None
+    if with_grad:
+        g1 = torch.empty((b, n, 3), dtype=torch.float32, device=dev)
+        g2 = torch.empty((b, m, 3), dtype=torch.float32, device=dev)
+        out += [g1, g2]
+    d1 = torch.empty((b, n), dtype=torch.float32, device=dev)  # per-point distances: scratch of the reduction
+    d2 = torch.empty((b, m), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_L.pcc_chamfer_emd(b, n, set_d.data_ptr(), m, set_q.data_ptr(), int(mean), loss.data_ptr(), d1.data_ptr(),
+                                      idx1.data_ptr(), d2.data_ptr(), idx2.data_ptr(), cost.data_ptr(),
+                                      g1.data_ptr() if with_grad else None, g2.data_ptr() if with_grad else None,
+                                      _stream(set_d)), 'ChamferEMD')
+    return out
+
+
 def _batch_stride(g: torch.Tensor, b: int) -> tuple[torch.Tensor, int]:
     """An upstream gradient [B] as (tensor, stride): one scalar expanded over the batch (what ``loss.sum().backward()``
     hands down) is read in place through stride 0, no copy kernel."""

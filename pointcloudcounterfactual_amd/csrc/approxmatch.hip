@@ -37,6 +37,7 @@
 #include "pcc_common.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 
 namespace {
@@ -76,6 +77,7 @@ enum Phase { PH_A = 0, PH_B = 1, PH_CA = 2, PH_C = 3 };
 
 constexpr int kDbgInts = 64 + 24 * 19;  // counters + per-phase stamps
 constexpr int kBox = 16;          // points per bounding-box block (sorted order)
+constexpr int kLiveRow = 16;      // ints per sample in the live-owner counters (one per level, padded)
 constexpr float kZeroExp = 151.f; // exp2(x) == 0 exactly for x <= -150 (below the smallest f32 subnormal)
 
 struct PhaseArgs {
@@ -85,6 +87,7 @@ struct PhaseArgs {
     const float *own_soa, *cand_soa;   // [b][3][n4] Hilbert-sorted coordinates
     const float *own_box, *cand_box;   // own: [b][ceil(n/64)][8] per 64 sorted points; cand: [b][nb][8] per 16 (min xyz,0,max xyz,0)
     int own_nb64;
+    const float *own_box16;            // [b][own_nb][8] per 16 sorted owners (am_fine_kernel)
     const float *w0, *w1;              // per-candidate weights in sorted order (w0 may be null => w0c)
     long long w0_stride, w1_stride;    // per-sample strides in floats
     float w0c;
@@ -104,6 +107,8 @@ struct PhaseArgs {
     float *clist;                      // dense candidate list [b][5][cl_n4]: x | y | z | ratioR | remainR (V_COWN writes, V_CLIST reads)
     int *clist_cnt;                    // [b] entries in the list
     int cl_n4;
+    const int *live_in;                // [b] live owners (remain != 0) of this pass B, counted by the previous pass B (V_COWN)
+    int *live_out;                     // [b] pass B: live owners of the next level's pass B (integer atomics: order-free)
     int *dbg;                          // optional [2] counters: blocks visited / skipped (debug builds of the host)
     int *stamp;                        // optional [3][8] s_memrealtime stamps of the first / middle / last workgroup (PCC_AM_DEBUG=2)
 };
@@ -134,6 +139,7 @@ struct Sched {
     float multiL, multiR, cut_scale;
     float *clist;                  // dense candidate list handed from pass B to pass C/A (null: pass C/A compacts itself)
     int *clist_cnt;
+    int *live_cnt;                 // [b][kLiveRow] live set2 points entering pass B of level i (zeroed by the sort; i >= 1)
     int skip;                      // work-skipping variants enabled
     LevelConsts lc;
     int *dbg;
@@ -152,9 +158,11 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
     if (set1_owns) {  // owners = set1, candidates = set2
         a.n_own = sc.n; a.n_cand = sc.m; a.own_n4 = sc.n4; a.cand_n4 = sc.m4; a.own_nb = sc.nb1; a.cand_nb = sc.nb2;
         a.own_soa = sc.soa1; a.cand_soa = sc.soa2; a.own_box = sc.box64_1; a.own_nb64 = sc.nb64_1; a.cand_box = sc.box2;
+        a.own_box16 = sc.box1;
     } else {          // owners = set2, candidates = set1
         a.n_own = sc.m; a.n_cand = sc.n; a.own_n4 = sc.m4; a.cand_n4 = sc.n4; a.own_nb = sc.nb2; a.cand_nb = sc.nb1;
         a.own_soa = sc.soa2; a.cand_soa = sc.soa1; a.own_box = sc.box64_2; a.own_nb64 = sc.nb64_2; a.cand_box = sc.box1;
+        a.own_box16 = sc.box2;
     }
     int mode, var;
     if (p == 0) {
@@ -182,6 +190,10 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
             a.remain_stride = rs;
             a.ratio_out = ratioR; a.ratio_stride = kLevels * nm4;
             if (var == V_COWN) { a.clist = sc.clist; a.clist_cnt = sc.clist_cnt; a.cl_n4 = sc.m4; }
+            if (sc.live_cnt) {  // strided by kLiveRow ints per sample: the kernels index [smp * kLiveRow]
+                a.live_in = (var == V_COWN && i >= 1) ? sc.live_cnt + i : nullptr;
+                a.live_out = i + 1 < kLevels ? sc.live_cnt + i + 1 : nullptr;
+            }
             a.dbg = sc.dbg_counts ? sc.dbg + 2 + 4 * i : nullptr;
         } else {           // pass C of level i (+ pass A of level i+1)
             mode = i + 1 < kLevels ? PH_CA : PH_C;
@@ -258,10 +270,15 @@ struct PhaseLds {
     static constexpr int floats = kC + kBB + kRed + kOwn + kWave + 4 + kItems;
 };
 
-template <int MODE, int R, int S, int CH, int VAR, bool PERSIST>
+// G > 1 (owner-compacted passes of the late levels only): a wave holds 64 / G owners, each on G lanes that split the
+// 16-candidate blocks among them (G-fold shorter pair loop for the few live owners left; the partial sums of the G
+// lanes meet through log2(G) shuffles, in a fixed order).
+template <int MODE, int R, int S, int CH, int VAR, bool PERSIST, int G = 1>
 __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int tile, float *smem) {
     constexpr int T = 64 * S;
-    constexpr int TQ = 64 * R;
+    constexpr int TQ = 64 * R / G;     // owners per workgroup
+    constexpr int PQ = 64 * R;         // pitch of the partial-sum rows in LDS
+    static_assert(G == 1 || (VAR == V_COWN && R == 1 && !PERSIST), "lane-split owners: owner-compacted launches only");
     constexpr int NW = (MODE == PH_CA) ? 2 : 1;
     constexpr bool W0_CONST = (MODE == PH_A);
     constexpr bool CULL = VAR == V_CULL, CCAND = VAR == V_CCAND, COWN = VAR == V_COWN, CLIST = VAR == V_CLIST;
@@ -279,6 +296,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = G > 1 ? lane / TQ : 0;  // which share of every candidate block this lane takes
     const float *O = a.own_soa + (size_t)smp * 3 * a.own_n4;
     const float *C = a.cand_soa + (size_t)smp * 3 * a.cand_n4;
     const float *W0 = W0_CONST ? nullptr : a.w0 + (size_t)smp * a.w0_stride;
@@ -383,7 +401,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     float t0x = 0.f, t1x = 0.f;  // second accumulators of the R == 1 shapes
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const int e = r * 64 + lane;
+        const int e = G > 1 ? (lane & (TQ - 1)) : r * 64 + lane;
         int o = COWN ? own_idx[e < n_valid ? e : 0] : tile * TQ + e;
         o = o < a.n_own ? o : a.n_own - 1;
         ox[r] = O[o];
@@ -572,7 +590,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
                 for (int r = 0; r < R; r++) live[r] = (item >> (16 + r)) & 1;
             }
             const int g_end = min(blk * 4 + 4, ngroups);
-            for (int g = blk * 4; g < g_end; g++) {
+            for (int g = blk * 4 + sub; g < g_end; g += G) {
                 const float4 x = X4[g], y = Y4[g], z = Z4[g], wa = A4[g];
                 float4 wb;
                 if (NW == 2) wb = B4[g];
@@ -618,10 +636,14 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         s0[0] += t0x;
         s1[0] += t1x;
     }
+    if (G > 1) {  // the G lanes of an owner: a + b is the same float on both sides, so all of them end with the same sum
+        s0[0] += __shfl_xor(s0[0], TQ, 64);
+        if (G == 4) s0[0] += __shfl_xor(s0[0], 2 * TQ, 64);
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        red[(0 * S + w) * TQ + r * 64 + lane] = s0[r];
-        if (NW == 2) red[(1 * S + w) * TQ + r * 64 + lane] = s1[r];
+        red[(0 * S + w) * PQ + r * 64 + lane] = s0[r];
+        if (NW == 2) red[(1 * S + w) * PQ + r * 64 + lane] = s1[r];
     }
     __syncthreads();
     PCC_ST(5);
@@ -630,11 +652,11 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         const int e = tid;
         const int o = own_e;
         float t0 = red[e], t1 = 0.f;
-        if (NW == 2) t1 = red[(1 * S) * TQ + e];
+        if (NW == 2) t1 = red[(1 * S) * PQ + e];
 #pragma unroll
         for (int s = 1; s < S; s++) {
-            t0 += red[(0 * S + s) * TQ + e];
-            if (NW == 2) t1 += red[(1 * S + s) * TQ + e];
+            t0 += red[(0 * S + s) * PQ + e];
+            if (NW == 2) t1 += red[(1 * S + s) * PQ + e];
         }
         if (MODE == PH_A) {
             // ratioL[k] = remainL[k] / (1e-9 + sum)            approxmatch.cu:37,61 (remainL == multiL)
@@ -647,6 +669,10 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             const float ratio_new = consumption * rR, remain_new = __builtin_fmaxf(0.0f, rR - sumr);
             xst<PERSIST>(&a.ratio_out[(size_t)smp * a.ratio_stride + o], ratio_new);
             xst<PERSIST>(&a.remain_out[(size_t)smp * a.remain_stride + o], remain_new);
+            if (!PERSIST && a.live_out) {  // owners still live after this level = the owner count of the next pass B
+                const unsigned long long alive = __ballot(remain_new != 0.f);
+                if (lane == 0) atomicAdd(&a.live_out[(size_t)smp * kLiveRow], (int)__popcll(alive));
+            }
             if (COWN && !PERSIST && a.clist) {
                 // this owner is the (tile * TQ + e)-th live one of its sample == its place in the next pass's candidate list
                 float cx = ox[0], cy = oy[0], cz = oz[0];  // thread e = w * 64 + lane holds owner e in slot r = w
@@ -679,7 +705,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
 }
 
 
-template <int MODE, int R, int S, int CH, int VAR>
+template <int MODE, int R, int S, int CH, int VAR, int G = 1>
 __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[PhaseLds<2, R, S, CH>::floats];
     // V_COWN packs the live owners into the low tiles: dispatch those first (tile-major order), so the workgroups
@@ -699,6 +725,9 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
             smp = bid % a.batch;
             tile = bid / a.batch;
         }
+        // the previous pass B counted the owners that are still live: workgroups beyond them leave at once (tile 0
+        // stays: it carries the zeros of the exhausted owners into the output buffer)
+        if (a.live_in && tile > 0 && tile * (64 * R / G) >= a.live_in[(size_t)smp * kLiveRow]) return;
     } else {
         int lid = bid;
         if (a.xcd && nwg > 8) {  // bijective swizzle: the blocks of one residue class get a contiguous run of logical ids
@@ -708,7 +737,206 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
         smp = lid / a.tiles;
         tile = lid - smp * a.tiles;
     }
-    am_phase_body<MODE, R, S, CH, VAR, false>(a, smp, tile, smem);
+    am_phase_body<MODE, R, S, CH, VAR, false, G>(a, smp, tile, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fine-grained culling for the passes of the fine levels (0-2, where the kernel radius is small against the cloud).
+// am_phase_kernel's V_CULL tests (64-owner group, 16-candidate block) pairs of boxes; on Hilbert-sorted clouds a run of
+// 64 points is several kernel radii wide, and 75-80 % of the pairs it keeps are still exact zeros.  Here a workgroup
+// still owns 64 consecutive sorted owners and stages the candidate cloud once, but the owners are tested and walked in
+// four groups of 16: a wave holds ONE group, each owner on 4 lanes that take one float4 (4 candidates) of every
+// surviving 16-candidate block, and two waves share the block list of a group.  Measured on the bench clouds the
+// (16 x 16) boxes keep 10 / 14 / 23 % of the pairs at levels 0 / 1 / 2 instead of 22 / 25 / 37 %.  Same sums as everywhere
+// else in this file: only exact zeros are dropped, partial sums meet in a fixed order (two accumulators per lane,
+// shuffles over the 4 lanes of an owner, the two waves of a group in LDS).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kFineS = 8;                // waves per workgroup
+constexpr int kFineOG = 16;              // owners per culling group (== kBox: the sort's 16-point boxes serve both sides)
+constexpr int kFineGroups = 64 / kFineOG;
+constexpr int kFineQ = 4;                // owners per lane
+
+template <int MODE, int CH>
+__global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
+    constexpr int T = 64 * kFineS;
+    constexpr int NW = (MODE == PH_CA) ? 2 : 1;
+    constexpr bool W0_CONST = (MODE == PH_A);
+    constexpr int NBLK = CH / kBox;      // candidate blocks per staged chunk
+    static_assert(kFineGroups * NBLK == T, "one (owner group, candidate block) box test per thread");
+    static_assert(kFineOG == kBox && kFineOG * kFineQ == 64, "a wave = 16 candidates x 4 owner quads");
+    __shared__ __attribute__((aligned(16))) float lds_c[(3 + NW) * CH];  // x | y | z | w0 | (w1)
+    __shared__ float red[NW][2][64];
+    __shared__ unsigned char items[kFineGroups][NBLK];
+    __shared__ unsigned char need[NBLK];
+    __shared__ int wave_cnt[kFineS];
+
+    int lid = (int)blockIdx.x;
+    const int nwg = (int)gridDim.x;
+    if (a.xcd && nwg > 8) {  // a sample's workgroups share an XCD (see am_phase_kernel)
+        const int q = nwg / 8, r = nwg % 8, x = lid % 8;
+        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + lid / 8;
+    }
+    const int smp = lid / a.tiles;
+    const int tile = lid - smp * a.tiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int og = w & (kFineGroups - 1);      // owner group of this wave
+    const int cs = w / kFineGroups;            // its share of the group's block list (0 / 1)
+    const int cl = lane & (kBox - 1);          // the candidate of a block this lane holds
+    const int quad = lane / kBox;              // its four owners: group-local 4 quad .. 4 quad + 3
+    const float *O = a.own_soa + (size_t)smp * 3 * a.own_n4;
+    const float *C = a.cand_soa + (size_t)smp * 3 * a.cand_n4;
+    const float *W0 = W0_CONST ? nullptr : a.w0 + (size_t)smp * a.w0_stride;
+    const float *W1 = (NW == 2) ? a.w1 + (size_t)smp * a.w1_stride : nullptr;
+
+    float ox[kFineQ], oy[kFineQ], oz[kFineQ], s0[kFineQ], s1[kFineQ];
+#pragma unroll
+    for (int j = 0; j < kFineQ; j++) {
+        int o = tile * 64 + og * kFineOG + quad * kFineQ + j;
+        o = o < a.n_own ? o : a.n_own - 1;
+        ox[j] = O[o];
+        oy[j] = O[a.own_n4 + o];
+        oz[j] = O[2 * a.own_n4 + o];
+        s0[j] = 0.f;
+        s1[j] = 0.f;
+    }
+    // epilogue operands (thread e < 64 finishes owner tile * 64 + e): fetched now, behind the staging traffic
+    const int own_e = (tid < 64 && tile * 64 + tid < a.n_own) ? tile * 64 + tid : -1;
+    float pre_rem = 0.f, pre_ratio = 0.f;
+    if (own_e >= 0) {
+        if (MODE != PH_A && !a.first) pre_rem = a.remain[(size_t)smp * a.remain_stride + own_e];
+        if (MODE == PH_CA || MODE == PH_C) pre_ratio = a.ratio_in[(size_t)smp * a.ratio_stride + own_e];
+    }
+    // box of the owner group this THREAD tests (thread = (group tg, candidate block tb))
+    const int tg = tid / NBLK, tb = tid - tg * NBLK;
+    float4 glo = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.f);
+    float4 ghi = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.f);
+    {
+        const int g16 = tile * kFineGroups + tg;
+        if (g16 < a.own_nb) {
+            const float4 *ob = reinterpret_cast<const float4 *>(a.own_box16 + ((size_t)smp * a.own_nb + g16) * 8);
+            glo = ob[0];
+            ghi = ob[1];
+        }
+    }
+    const float c0 = a.c0, c1 = a.c1, cut2 = a.cut2;
+
+    for (int q0 = 0; q0 < a.n_cand; q0 += CH) {
+        const int cnt = min(CH, a.n_cand - q0);
+        const int ngroups = (cnt + 3) / 4;
+        const int nblk = (ngroups + 3) / 4;
+        if (q0) __syncthreads();
+        if (tid < NBLK) need[tid] = 0;
+        // one box test per thread; the surviving blocks of a group are compacted, in order, into its list (the two
+        // waves that hold the flags of a group: 2 tg and 2 tg + 1)
+        bool keep = false;
+        if (tb < nblk) {
+            const float4 *cb = reinterpret_cast<const float4 *>(a.cand_box + ((size_t)smp * a.cand_nb + q0 / kBox + tb) * 8);
+            const float4 lo = cb[0], hi = cb[1];
+            const float dx = fmaxf(fmaxf(glo.x - hi.x, lo.x - ghi.x), 0.f);
+            const float dy = fmaxf(fmaxf(glo.y - hi.y, lo.y - ghi.y), 0.f);
+            const float dz = fmaxf(fmaxf(glo.z - hi.z, lo.z - ghi.z), 0.f);
+            keep = !(dx * dx + dy * dy + dz * dz > cut2);  // farther: every exponential of the pair of boxes is exactly 0
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wave_cnt[w] = __popcll(bal);
+        __syncthreads();
+        {
+            const int before = (w & 1) ? wave_cnt[w - 1] : 0;
+            if (keep) {
+                items[tg][before + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)tb;
+                need[tb] = 1;  // (same value from every writer)
+            }
+        }
+        __syncthreads();
+        {   // stage the blocks some group of this workgroup needs (on the fine levels a fraction of the cloud): the sorted
+            // SoA rows and weight rows are padded to a multiple of 4 (zeros), so these are straight float4 copies
+            float4 *dst4 = reinterpret_cast<float4 *>(lds_c);
+            const float4 *sx = reinterpret_cast<const float4 *>(C + q0);
+            const float4 *sy = reinterpret_cast<const float4 *>(C + (size_t)a.cand_n4 + q0);
+            const float4 *sz = reinterpret_cast<const float4 *>(C + (size_t)2 * a.cand_n4 + q0);
+            for (int i = tid; i < nblk * 4; i += T) {
+                if (!need[i >> 2]) continue;
+                float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vy = vx, vz = vx, v0 = vx, v1 = vx;
+                if (i < ngroups) {
+                    vx = sx[i]; vy = sy[i]; vz = sz[i];
+                    v0 = W0_CONST ? make_float4(a.w0c, a.w0c, a.w0c, a.w0c) : *reinterpret_cast<const float4 *>(W0 + q0 + 4 * i);
+                    if (NW == 2) v1 = *reinterpret_cast<const float4 *>(W1 + q0 + 4 * i);
+                    if (W0_CONST && i * 4 + 3 >= cnt) {  // padded candidates must weigh 0
+                        v0.x = i * 4 + 0 < cnt ? v0.x : 0.f;
+                        v0.y = i * 4 + 1 < cnt ? v0.y : 0.f;
+                        v0.z = i * 4 + 2 < cnt ? v0.z : 0.f;
+                        v0.w = 0.f;
+                    }
+                }
+                dst4[i] = vx;
+                dst4[CH / 4 + i] = vy;
+                dst4[2 * (CH / 4) + i] = vz;
+                dst4[3 * (CH / 4) + i] = v0;
+                if (NW == 2) dst4[4 * (CH / 4) + i] = v1;
+            }
+        }
+        __syncthreads();
+        // a wave walks its half of the group's block list: a lane holds ONE candidate of the block (five scalar LDS
+        // reads, 16 distinct addresses per wave) against its four owners in registers -- four independent fma chains
+        const int nitems = wave_cnt[2 * og] + wave_cnt[2 * og + 1];
+        for (int it = cs; it < nitems; it += 2) {
+            const int ci = __builtin_amdgcn_readfirstlane((int)items[og][it]) * kBox + cl;
+            const float x = lds_c[ci], y = lds_c[CH + ci], z = lds_c[2 * CH + ci], wa = lds_c[3 * CH + ci];
+            float wb = 0.f;
+            if (NW == 2) wb = lds_c[4 * CH + ci];
+#pragma unroll
+            for (int j = 0; j < kFineQ; j++) {
+                const float d = sq3(x - ox[j], y - oy[j], z - oz[j]);
+                s0[j] = __builtin_fmaf(fast_exp2(c0 * d), wa, s0[j]);
+                if (NW == 2) s1[j] = __builtin_fmaf(fast_exp2(c1 * d), wb, s1[j]);
+            }
+        }
+    }
+    // the 16 candidate lanes of an owner meet through four butterfly steps (a + b is the same float on both sides, so
+    // every lane ends with the same sum); lane cl == 0 of each quad hands the four sums to the epilogue
+#pragma unroll
+    for (int j = 0; j < kFineQ; j++) {
+#pragma unroll
+        for (int off = 1; off < kBox; off <<= 1) {
+            s0[j] += __shfl_xor(s0[j], off, 64);
+            if (NW == 2) s1[j] += __shfl_xor(s1[j], off, 64);
+        }
+    }
+    if (cl == 0) {
+#pragma unroll
+        for (int j = 0; j < kFineQ; j++) {
+            red[0][cs][og * kFineOG + quad * kFineQ + j] = s0[j];
+            if (NW == 2) red[NW - 1][cs][og * kFineOG + quad * kFineQ + j] = s1[j];
+        }
+    }
+    __syncthreads();
+    if (own_e < 0) return;
+    const float sum0 = red[0][0][tid] + red[0][1][tid];
+    const float sum1 = NW == 2 ? red[NW - 1][0][tid] + red[NW - 1][1][tid] : 0.f;
+    if (MODE == PH_A) {
+        // ratioL[k] = remainL[k] / (1e-9 + sum)            approxmatch.cu:37,61 (remainL == multiL)
+        a.ratio_out[(size_t)smp * a.ratio_stride + own_e] = a.multiL / (1e-9f + sum0);
+    } else if (MODE == PH_B) {
+        // approxmatch.cu:106-109
+        const float rR = a.first ? a.multiR : pre_rem;
+        const float sumr = sum0 * rR;
+        const float consumption = __builtin_fminf(rR / (sumr + 1e-9f), 1.0f);
+        const float ratio_new = consumption * rR, remain_new = __builtin_fmaxf(0.0f, rR - sumr);
+        a.ratio_out[(size_t)smp * a.ratio_stride + own_e] = ratio_new;
+        a.remain_out[(size_t)smp * a.remain_stride + own_e] = remain_new;
+        if (a.live_out) {  // owners still live after this level = the owner count of the next pass B
+            const unsigned long long alive = __ballot(remain_new != 0.f);
+            if (lane == 0) atomicAdd(&a.live_out[(size_t)smp * kLiveRow], (int)__popcll(alive));
+        }
+    } else {
+        // pass C: suml = sum_l e*ratioL[k]*ratioR[l] ; remainL = max(0, remainL - suml)   :154-162
+        const float rL = a.first ? a.multiL : pre_rem;
+        const float left = __builtin_fmaxf(0.0f, rL - pre_ratio * sum0);
+        a.remain[(size_t)smp * a.remain_stride + own_e] = left;
+        // pass A of the next level: ratioL' = remainL / (1e-9 + sum_l e'*remainR[l])       :37,61
+        if (MODE == PH_CA) a.ratio_out[(size_t)smp * a.ratio_stride + own_e] = left / (1e-9f + sum1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -826,12 +1054,14 @@ struct SortArgs {  // one entry per cloud; blockIdx.y selects it
     const float *xyz[2];
     float *soa[2];
     int *rank[2];
+    int *perm[2];      // sorted position -> original index (inverse of rank)
     float *box[2];
     float *box64[2];
     int nb64[2];
     // zero-fill riding along (replaces two memset launches): the two workgroups of a sample clear one region each
     float *zero[2];
     long long zero_stride[2], zero_count[2];  // per-sample stride and length in floats (multiples of 4)
+    int *live_cnt;                            // [b][kLiveRow] live-owner counters of the passes B, cleared here
 };
 
 // Bitonic sort of NPAD = kSortT*SLOTS 32-bit keys held in registers (element i = tid + kSortT*slot) by a
@@ -886,6 +1116,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     const int which = blockIdx.y;
     const int n = a.n[which], n4 = a.n4[which], nb = a.nb[which], npad = a.npad[which];
     const int smp = blockIdx.x, tid = threadIdx.x, T = kSortT;
+    if (a.live_cnt && which == 0 && threadIdx.x < kLiveRow) a.live_cnt[(size_t)blockIdx.x * kLiveRow + threadIdx.x] = 0;
     if (a.zero[which]) {  // fire-and-forget stores, hidden under the sort
         float4 *z = reinterpret_cast<float4 *>(a.zero[which] + (size_t)smp * a.zero_stride[which]);
         const long long cnt4 = a.zero_count[which] / 4;
@@ -894,6 +1125,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     const float *p = a.xyz[which] + (size_t)smp * n * 3;
     float *so = a.soa[which] + (size_t)smp * 3 * n4;
     int *rk = a.rank[which] + (size_t)smp * n;
+    int *pm = a.perm[which] + (size_t)smp * n;
     float *bx = a.box[which] + (size_t)smp * nb * 8;
     float *bx64 = a.box64[which] + (size_t)smp * a.nb64[which] * 8;
     int idx_bits = 10;
@@ -963,6 +1195,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
             y = p[orig * 3 + 1];
             z = p[orig * 3 + 2];
             rk[orig] = s;
+            pm[s] = orig;
         }
         if (s < n4) {
             so[s] = x;
@@ -1716,7 +1949,7 @@ __global__ __launch_bounds__(256) void am_pair_kernel(PairArgs a) {
 struct FinishArgs {
     int parts[3], npts[2], pitch[2];
     const float *part[3];
-    const int *rank[2];
+    const int *perm[2];   // sorted position -> caller's point index
     const float *scale;
     float *out[3];
 };
@@ -1738,15 +1971,17 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
         return;
     }
     if (!f.out[which]) return;
+    // a thread owns component c of SORTED position s: the partial rows are read as straight coalesced streams (they
+    // are the bulk: parts x npts x 12 bytes); only the 12-byte result is scattered to the caller's point order
     const int npts = f.npts[which], pitch = f.pitch[which], parts = f.parts[which];
     const int i = blockIdx.x * 256 + tid;
     if (i >= npts * 3) return;
-    const int pt = i / 3, c = i - pt * 3;
-    const int s = f.rank[which][(size_t)smp * npts + pt];
-    const float *p = f.part[which] + ((size_t)smp * parts * pitch + s) * 3 + c;
+    const int s = i / 3, c = i - s * 3;
+    const float *p = f.part[which] + (size_t)smp * parts * pitch * 3 + i;
     float acc = p[0];
     for (int t = 1; t < parts; t++) acc += p[(size_t)t * pitch * 3];
-    f.out[which][(size_t)smp * npts * 3 + i] = f.scale ? acc * f.scale[smp] : acc;
+    const int pt = f.perm[which][(size_t)smp * npts + s];
+    f.out[which][((size_t)smp * npts + pt) * 3 + c] = f.scale ? acc * f.scale[smp] : acc;
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -1784,9 +2019,9 @@ const char *phase_name(int level) {
     return names[MODE][level];
 }
 
-template <int MODE, int R, int S>
+template <int MODE, int R, int S, int G = 1>
 int launch_phase_rs(PhaseArgs a, int b, int var, hipStream_t st, const char *what) {
-    a.tiles = pcc::ceil_div(a.n_own, 64 * R);
+    a.tiles = pcc::ceil_div(a.n_own, 64 * R / G);
     a.batch = b;
     static const int xcd_on = [] {
         const char *e = std::getenv("PCC_AM_NOXCD");
@@ -1805,14 +2040,38 @@ int launch_phase_rs(PhaseArgs a, int b, int var, hipStream_t st, const char *wha
         else if (var == V_CLIST && (MODE == PH_CA || MODE == PH_C))
             hipLaunchKernelGGL((am_phase_kernel<(MODE == PH_CA || MODE == PH_C) ? MODE : PH_C, R, S, kPhCH, V_CLIST>), g, blk, 0, st, a);
         else if (var == V_COWN && MODE == PH_B)
-            hipLaunchKernelGGL((am_phase_kernel<PH_B, R, S, kPhCH, V_COWN>), g, blk, 0, st, a);
+            hipLaunchKernelGGL((am_phase_kernel<PH_B, (G > 1 ? 1 : R), S, kPhCH, V_COWN, G>), g, blk, 0, st, a);
         else hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, V_PLAIN>), g, blk, 0, st, a);
     }
     return pcc::check_launch(what);
 }
 
 template <int MODE>
+int launch_fine(PhaseArgs a, int b, hipStream_t st, const char *what) {
+    a.tiles = pcc::ceil_div(a.n_own, 64);
+    a.batch = b;
+    static const int xcd_on = [] {
+        const char *e = std::getenv("PCC_AM_NOXCD");
+        return (e && e[0] == '1') ? 0 : 1;
+    }();
+    a.xcd = xcd_on;
+    const long long grid = (long long)b * a.tiles;
+    if (grid > 0x7fffffffLL) return pcc::invalid("approxmatch: grid too large");
+    {
+        pcc::ProfScope prof(phase_name<MODE>(a.level), st);
+        hipLaunchKernelGGL((am_fine_kernel<(MODE == PH_C ? PH_CA : MODE), kPhCH>), dim3((unsigned)grid), dim3(64 * kFineS), 0, st, a);
+    }
+    return pcc::check_launch(what);
+}
+
+template <int MODE>
 int launch_phase(const PhaseArgs &a, int b, int var, hipStream_t st, const char *what) {
+    // the box-culled passes of the fine levels: 16-owner groups (am_fine_kernel) unless PCC_AM_FINE=0
+    static const int fine_on = [] {
+        const char *e = std::getenv("PCC_AM_FINE");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    if (var == V_CULL && fine_on && MODE != PH_C) return launch_fine<MODE>(a, b, st, what);
     int cfg = phase_cfg_override();
     if (cfg == 0) {
         const long long owners = (long long)b * a.n_own;
@@ -1831,6 +2090,14 @@ int launch_phase(const PhaseArgs &a, int b, int var, hipStream_t st, const char 
             const char *e = std::getenv("PCC_AM_COWN_CFG");
             return e ? std::atoi(e) : 18;
         }();
+        // lane-split owners where few are left (recon / uniform clouds: ~25 % live at level 5, 5 % at level 8): the
+        // pair loop of a workgroup, which is the launch's critical path, gets G times shorter
+        static const int g_from[2] = {[] { const char *e = std::getenv("PCC_AM_G2_FROM"); return e ? std::atoi(e) : 4; }(),
+                                      [] { const char *e = std::getenv("PCC_AM_G4_FROM"); return e ? std::atoi(e) : 5; }()};
+        if (MODE == PH_B && cown_cfg == 18 && a.live_in) {
+            if (a.level >= g_from[1]) return launch_phase_rs<MODE, 1, 8, 4>(a, b, var, st, what);
+            if (a.level >= g_from[0]) return launch_phase_rs<MODE, 1, 8, 2>(a, b, var, st, what);
+        }
         switch (cown_cfg) {
         case 116: return launch_phase_rs<MODE, 1, 16>(a, b, var, st, what);
         case 18: return launch_phase_rs<MODE, 1, 8>(a, b, var, st, what);
@@ -1882,7 +2149,7 @@ size_t cost_parts(int n, int m) { return (size_t)pcc::ceil_div(n, kMatKT) * pcc:
 // Workspace carve (bytes, every section 16-byte aligned).
 struct WsLayout {
     int n4, m4, nb1, nb2, nb64_1, nb64_2;
-    size_t soa1, soa2, rank1, rank2, box1, box2, box64_1, box64_2, rem, lv, lv_orig, cpart, sync, clist, clist_cnt, total;
+    size_t soa1, soa2, rank1, rank2, perm1, perm2, box1, box2, box64_1, box64_2, rem, lv, lv_orig, cpart, sync, clist, clist_cnt, live_cnt, total;
     WsLayout(int b, int n, int m) {
         auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
         n4 = (n + 3) & ~3;
@@ -1896,6 +2163,8 @@ struct WsLayout {
         soa2 = o; o = up(o + (size_t)b * 3 * m4 * 4);
         rank1 = o; o = up(o + (size_t)b * n * 4);
         rank2 = o; o = up(o + (size_t)b * m * 4);
+        perm1 = o; o = up(o + (size_t)b * n * 4);
+        perm2 = o; o = up(o + (size_t)b * m * 4);
         box1 = o; o = up(o + (size_t)b * nb1 * 8 * 4);
         box2 = o; o = up(o + (size_t)b * nb2 * 8 * 4);
         box64_1 = o; o = up(o + (size_t)b * nb64_1 * 8 * 4);
@@ -1907,14 +2176,16 @@ struct WsLayout {
         sync = o; o = up(o + ((size_t)b + 1) * 4);   // per-sample barrier counters + error word (persistent kernel)
         clist = o; o = up(o + (size_t)b * 5 * m4 * 4);   // dense candidate list handed from pass B to pass C/A
         clist_cnt = o; o = up(o + (size_t)b * 4);
+        live_cnt = o; o = up(o + (size_t)b * kLiveRow * 4);
         total = o;
     }
 };
 
 int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const float *xyz2, float *soa1, float *soa2,
-                int *rank1, int *rank2, float *box1, float *box2, float *box64_1, float *box64_2, float *rem, float *lv,
-                hipStream_t st) {
+                int *rank1, int *rank2, int *perm1, int *perm2, float *box1, float *box2, float *box64_1, float *box64_2, float *rem, float *lv,
+                int *live_cnt, hipStream_t st) {
     SortArgs a{};
+    a.live_cnt = live_cnt;
     // the padded tails of the weight rows are staged as float4: they must be finite (their candidates sit at the
     // origin with these weights), and V_COWN relies on zero-filled level arrays for the exhausted owners it never
     // touches: remain rows are cleared by the workgroup sorting set1, level rows by the one sorting set2
@@ -1934,7 +2205,7 @@ int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const
         if (a.npad[w]) a.npad[w] = kSortT * slots;  // one SLOTS instantiation serves both clouds
     a.n4[0] = L.n4; a.n4[1] = L.m4; a.nb[0] = L.nb1; a.nb[1] = L.nb2;
     a.xyz[0] = xyz1; a.xyz[1] = xyz2; a.soa[0] = soa1; a.soa[1] = soa2;
-    a.rank[0] = rank1; a.rank[1] = rank2; a.box[0] = box1; a.box[1] = box2;
+    a.rank[0] = rank1; a.rank[1] = rank2; a.perm[0] = perm1; a.perm[1] = perm2; a.box[0] = box1; a.box[1] = box2;
     a.box64[0] = box64_1; a.box64[1] = box64_2; a.nb64[0] = L.nb64_1; a.nb64[1] = L.nb64_2;
     pcc::ProfScope prof("am_sort_kernel", st);
     const dim3 grid(b, 2);
@@ -1991,7 +2262,7 @@ struct ForkJoin {  // side waits for everything enqueued on main so far; at scop
 // Sort + the 19 passes: leaves the nine (ratioL | ratioR) level rows and remainL | remainR in the workspace, in the
 // Hilbert-sorted index space.
 int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const WsLayout &L, char *base, hipStream_t st,
-               bool *persist_out) {
+               bool *persist_out, const std::function<int(int, int, hipStream_t)> &lane_tail = nullptr) {
     const LevelConsts lc = make_levels();
     float multiL, multiR;  // approxmatch.cu:6-12 (integer division)
     if (n >= m) { multiL = 1; multiR = (float)(n / m); }
@@ -2076,11 +2347,7 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
             (void)hipGetLastError();
             cap = hipStreamCaptureStatusNone;
         }
-        static const bool lanes_in_capture = [] {  // PCC_AM_CAPTURE_LANES=1: fork/join inside a capture (A/B measurements)
-            const char *e = std::getenv("PCC_AM_CAPTURE_LANES");
-            return e && e[0] == '1';
-        }();
-        if (cap == hipStreamCaptureStatusNone || lanes_in_capture) side = side_stream(0);
+        if (cap == hipStreamCaptureStatusNone) side = side_stream(0);
     }
     ForkJoin fj(st, side);
     ForkJoin fj2(st, fj.ok && want_lanes >= 3 ? side_stream(1) : nullptr);
@@ -2112,6 +2379,7 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
             sc.clist = reinterpret_cast<float *>(base + L.clist) + s0 * 5 * L.m4;
             sc.clist_cnt = reinterpret_cast<int *>(base + L.clist_cnt) + s0;
         }
+        if (!use_persist && sc.skip) sc.live_cnt = reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow;
     }
     int rc = PCC_OK;
     for (int l = 0; l < nlanes && !rc; l++) {
@@ -2119,9 +2387,11 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         const size_t s0 = (size_t)ln.s0;
         rc = sort_clouds(ln.bc, L, n, m, xyz1 + s0 * n * 3, xyz2 + s0 * m * 3, const_cast<float *>(ln.sc.soa1),
                          const_cast<float *>(ln.sc.soa2), reinterpret_cast<int *>(base + L.rank1) + s0 * n,
-                         reinterpret_cast<int *>(base + L.rank2) + s0 * m, const_cast<float *>(ln.sc.box1),
+                         reinterpret_cast<int *>(base + L.rank2) + s0 * m, reinterpret_cast<int *>(base + L.perm1) + s0 * n,
+                         reinterpret_cast<int *>(base + L.perm2) + s0 * m, const_cast<float *>(ln.sc.box1),
                          const_cast<float *>(ln.sc.box2), const_cast<float *>(ln.sc.box64_1),
-                         const_cast<float *>(ln.sc.box64_2), ln.sc.rem, ln.sc.lv, ln.st);
+                         const_cast<float *>(ln.sc.box64_2), ln.sc.rem, ln.sc.lv,
+                         reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow, ln.st);
     }
     if (rc) return rc;
 
@@ -2149,6 +2419,13 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
                 const Lane &ln = lanes[l];
                 int mode, var;
                 const PhaseArgs a = build_phase(ln.sc, p, &mode, &var);
+                // pass C of level 2 + pass A of level 3: the (16 x 16) boxes still drop half of the pairs at level 3's
+                // radius, more than compacting away the exhausted candidates does (PCC_AM_FINE_CA2=0: the latter)
+                static const int fine_ca2 = [] {
+                    const char *e = std::getenv("PCC_AM_FINE_CA2");
+                    return (e && e[0] == '0') ? 0 : 1;
+                }();
+                if (fine_ca2 && mode == PH_CA && a.level == 2 && var == V_CCAND) var = V_CULL;
                 switch (mode) {
                 case PH_A: rc = launch_phase<PH_A>(a, ln.bc, var, ln.st, "approxmatch(A)"); break;
                 case PH_B: rc = launch_phase<PH_B>(a, ln.bc, var, ln.st, "approxmatch(B)"); break;
@@ -2158,6 +2435,12 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
             }
         }
         if (rc) return rc;
+    }
+    // what follows the passes for one lane's samples (the implicit path's pair + finish kernels) goes on that lane's
+    // stream: the lane that finishes its passes first starts at once instead of waiting for the join
+    if (lane_tail) {
+        for (int l = 0; l < nlanes; l++)
+            if (int rc2 = lane_tail(lanes[l].s0, lanes[l].bc, lanes[l].st)) return rc2;
     }
     if (dbg_counters) {
         static int h[kDbgInts];
@@ -2252,36 +2535,41 @@ int match_cost_implicit_impl(int b, int n, int m, const float *xyz1, const float
     StreamBuf ws(st);
     if (int rc = ws.alloc(total)) return rc;
     char *base = static_cast<char *>(ws.p);
+    const size_t nm4 = (size_t)L.n4 + L.m4;
+    // pair + finish kernels of the samples [s0, s0 + bc) on `lst` (every section of the workspace is indexed by sample)
+    auto tail = [&](int s0, int bc, hipStream_t lst) -> int {
+        const size_t o = (size_t)s0;
+        PairArgs pa{};
+        pa.n = n; pa.m = m; pa.n4 = L.n4; pa.m4 = L.m4;
+        pa.soa1 = reinterpret_cast<const float *>(base + L.soa1) + o * 3 * L.n4;
+        pa.soa2 = reinterpret_cast<const float *>(base + L.soa2) + o * 3 * L.m4;
+        pa.lv = reinterpret_cast<const float *>(base + L.lv) + o * kLevels * nm4;
+        pa.lc = make_levels();
+        for (int i = 0; i < kLevels; i++) pa.cut2[i] = kZeroExp / -pa.lc.c[i];
+        pa.cost_part = reinterpret_cast<float *>(base + cpart_off) + o * col_blocks * row_tiles;
+        pa.part1 = grad ? reinterpret_cast<float *>(base + part1_off) + o * row_tiles * L.n4 * 3 : nullptr;
+        pa.part2 = grad ? reinterpret_cast<float *>(base + part2_off) + o * col_blocks * L.m4 * 3 : nullptr;
+        const dim3 grid(col_blocks, row_tiles, bc);
+        if (int rc = q_cols == 2 ? launch_pair<2>(pa, grid, grad, lst) : launch_pair<4>(pa, grid, grad, lst)) return rc;
+        FinishArgs f{};
+        f.parts[0] = row_tiles; f.parts[1] = col_blocks; f.parts[2] = col_blocks * row_tiles;
+        f.npts[0] = n; f.npts[1] = m; f.pitch[0] = L.n4; f.pitch[1] = L.m4;
+        f.part[0] = pa.part1; f.part[1] = pa.part2; f.part[2] = pa.cost_part;
+        f.perm[0] = reinterpret_cast<const int *>(base + L.perm1) + o * n;
+        f.perm[1] = reinterpret_cast<const int *>(base + L.perm2) + o * m;
+        f.scale = grad_cost ? grad_cost + o : nullptr;
+        f.out[0] = grad ? grad1 + o * n * 3 : nullptr;
+        f.out[1] = grad ? grad2 + o * m * 3 : nullptr;
+        f.out[2] = cost + o;
+        {
+            pcc::ProfScope prof("pair_finish_kernel", lst);
+            const int blocks = grad ? pcc::ceil_div(std::max(n, m) * 3, 256) : 1;
+            hipLaunchKernelGGL(pair_finish_kernel, dim3(blocks, bc, 3), dim3(256), 0, lst, f);
+        }
+        return pcc::check_launch("match_cost(reduce)");
+    };
     bool use_persist = false;
-    int rc = run_levels(b, n, m, xyz1, xyz2, L, base, st, &use_persist);
-    if (rc) return rc;
-    PairArgs pa{};
-    pa.n = n; pa.m = m; pa.n4 = L.n4; pa.m4 = L.m4;
-    pa.soa1 = reinterpret_cast<const float *>(base + L.soa1);
-    pa.soa2 = reinterpret_cast<const float *>(base + L.soa2);
-    pa.lv = reinterpret_cast<const float *>(base + L.lv);
-    pa.lc = make_levels();
-    for (int i = 0; i < kLevels; i++) pa.cut2[i] = kZeroExp / -pa.lc.c[i];
-    pa.cost_part = reinterpret_cast<float *>(base + cpart_off);
-    pa.part1 = grad ? reinterpret_cast<float *>(base + part1_off) : nullptr;
-    pa.part2 = grad ? reinterpret_cast<float *>(base + part2_off) : nullptr;
-    const dim3 grid(col_blocks, row_tiles, b);
-    rc = q_cols == 2 ? launch_pair<2>(pa, grid, grad, st) : launch_pair<4>(pa, grid, grad, st);
-    if (rc) return rc;
-    FinishArgs f{};
-    f.parts[0] = row_tiles; f.parts[1] = col_blocks; f.parts[2] = col_blocks * row_tiles;
-    f.npts[0] = n; f.npts[1] = m; f.pitch[0] = L.n4; f.pitch[1] = L.m4;
-    f.part[0] = pa.part1; f.part[1] = pa.part2; f.part[2] = pa.cost_part;
-    f.rank[0] = reinterpret_cast<const int *>(base + L.rank1);
-    f.rank[1] = reinterpret_cast<const int *>(base + L.rank2);
-    f.scale = grad_cost;
-    f.out[0] = grad ? grad1 : nullptr; f.out[1] = grad ? grad2 : nullptr; f.out[2] = cost;
-    {
-        pcc::ProfScope prof("pair_finish_kernel", st);
-        const int blocks = grad ? pcc::ceil_div(std::max(n, m) * 3, 256) : 1;
-        hipLaunchKernelGGL(pair_finish_kernel, dim3(blocks, b, 3), dim3(256), 0, st, f);
-    }
-    return pcc::check_launch("match_cost(reduce)");
+    return run_levels(b, n, m, xyz1, xyz2, L, base, st, &use_persist, tail);
 }
 
 int check_sizes(const char *who, int b, int n, int m) {

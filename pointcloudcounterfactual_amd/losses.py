@@ -136,26 +136,16 @@ def chamfer(t1: torch.Tensor, t2: torch.Tensor, reduction: str = 'mean') -> torc
     return ChamferFunction.apply(t1, t2, reduction == 'mean')
 
 
-_side_streams: dict[int, torch.cuda.Stream] = {}
-
-
-def _side_stream(dev: torch.device) -> torch.cuda.Stream:
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    st = _side_streams.get(idx)
-    if st is None:
-        st = _side_streams[idx] = torch.cuda.Stream(device=dev)
-    return st
-
-
 class ChamferEMDFunction(Function):
     """``(t1[B,N,3], t2[B,M,3], mean) -> (chamfer[B], emd[B])``: the two terms of the reference's ``ChamferEMD``
     reconstruction loss (``src/train/metrics_and_losses.py:70-79``: Chamfer and ``match_cost`` on the SAME pair of
     clouds) as one autograd node.  Same kernels and the same bits as ``chamfer(t1, t2)`` and ``match_cost(t1, t2)``;
     what the fusion buys is scheduling:
 
-    * forward: the two losses do not depend on each other, and the approximate EMD is a chain of 19 dependent,
-      latency-bound launches that leaves most of the chip idle.  The nearest-neighbour search (VALU-bound, one big
-      launch) is enqueued on a side stream and runs in that shadow; the side stream joins before the node returns.
+    * forward: the two losses do not depend on each other, and the approximate EMD is a chain of 19 dependent
+      launches whose late passes are latency-bound and leave most of the chip idle.  One library call
+      (``pcc_chamfer_emd``) enqueues the nearest-neighbour search (VALU-bound, one big launch) on an internal stream
+      that starts when the chain reaches those passes, and joins it before returning.
     * backward: one launch (``pcc_chamfer_emd_grad``) writes the total gradient -- Chamfer's scatter term plus the
       saved ``match_cost`` gradients times their upstream scalar -- instead of three launches and two accumulations.
     """
@@ -163,26 +153,12 @@ class ChamferEMDFunction(Function):
     @staticmethod
     def forward(ctx: Any, *args: Any, **kwargs: Any) -> Any:
         t1, t2, mean = args
-        dev = t1.device
         with_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
-        overlap = t1.is_cuda and not torch.cuda.is_current_stream_capturing()
-        if overlap:
-            cur = torch.cuda.current_stream(dev)
-            side = _side_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                loss, _d1, idx1, _d2, idx2 = backend.ChamferLoss(t1, t2, bool(mean))
-            out = backend.MatchCostImplicit(t1, t2, with_grad)
-            cur.wait_stream(side)
-            for t in (loss, idx1, idx2, _d1, _d2):  # allocated on the side stream, consumed / freed on this one
-                t.record_stream(cur)
-        else:
-            loss, _d1, idx1, _d2, idx2 = backend.ChamferLoss(t1, t2, bool(mean))
-            out = backend.MatchCostImplicit(t1, t2, with_grad)
+        out = backend.ChamferEMD(t1, t2, bool(mean), with_grad)
         if with_grad:
-            ctx.save_for_backward(t1, t2, idx1, idx2, out[1], out[2])
+            ctx.save_for_backward(t1, t2, out[1], out[2], out[4], out[5])
         ctx.mean = bool(mean)
-        return loss, out[0]
+        return out[0], out[3]
 
     @staticmethod
     def backward(ctx: Any, *grad_outputs: Any) -> Any:

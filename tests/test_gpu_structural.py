@@ -568,7 +568,10 @@ def test_chamfer_emd_node_equals_separate_losses(cuda, b, n, m, reduction):
         ref = rc + 0.5 * re
         (ref.sum() if weights is None else (ref * weights).sum()).backward()
         assert torch.equal(lc, rc) and torch.equal(le, re)
-        assert torch.equal(t1.grad, u1.grad) and torch.equal(t2.grad, u2.grad)
+        # same products, same sums; the Chamfer scatter term accumulates with LDS float atomics whose order is free when
+        # three or more neighbours share a target (as in pcc_nndistancegrad itself): rounding-level differences only
+        for got, exp in ((t1.grad, u1.grad), (t2.grad, u2.grad)):
+            np.testing.assert_allclose(got.cpu().numpy(), exp.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(exp.abs().max()))
     # only one input requires a gradient / none does
     t1 = _dev(a, cuda).requires_grad_(True)
     lc, le = chamfer_emd(t1, _dev(c, cuda), reduction)
@@ -576,4 +579,6 @@ def test_chamfer_emd_node_equals_separate_losses(cuda, b, n, m, reduction):
     assert t1.grad is not None and torch.isfinite(t1.grad).all()
     with torch.no_grad():
         lc2, le2 = chamfer_emd(_dev(a, cuda), _dev(c, cuda), reduction)
-    assert torch.equal(lc2, lc) and torch.equal(le2, le)
+    assert torch.equal(lc2, lc)
+    # the cost-only kernel takes sqrt(d2) directly, the gradient variant as d2 * rsqrt(d2): 2e-6, as for match_cost
+    np.testing.assert_allclose(le2.cpu().numpy(), le.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)

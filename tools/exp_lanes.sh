@@ -9,9 +9,6 @@ run PCC_AM_NOSPLIT=1
 run PCC_AM_LANES=2
 run PCC_AM_LANES=3
 run PCC_AM_LANES=4
-run PCC_AM_LANES=2 PCC_AM_CAPTURE_LANES=1
-run PCC_AM_LANES=3 PCC_AM_CAPTURE_LANES=1
-run PCC_AM_LANES=4 PCC_AM_CAPTURE_LANES=1
 run PCC_AM_NOCULL=1 PCC_EXP_GRAPH=0
 timeout -k 10 120 env PCC_EXP_GRAPH=0 python3 tools/exp_lanes.py uniform >> $O 2>&1
 timeout -k 10 120 env PCC_EXP_GRAPH=0 PCC_AM_NOCULL=1 python3 tools/exp_lanes.py uniform >> $O 2>&1
