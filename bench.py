@@ -63,6 +63,7 @@ def parse() -> argparse.Namespace:
     ap.add_argument('--via-launcher', action='store_true',
                     help='start the ranks through torch.distributed.run even for --gpus 1 (exercises RCCL at world 1)')
     ap.add_argument('--phase-probe', action='store_true', help=argparse.SUPPRESS)  # child of the no-skip measurement
+    ap.add_argument('--no-dist-init', action='store_true', help=argparse.SUPPRESS)  # diagnosis: launcher without RCCL
     ap.add_argument('--kind', choices=['recon', 'uniform'], default='recon', help=argparse.SUPPRESS)
     ap.add_argument('--emd-mode', choices=['implicit', 'fused', 'reference'], default='implicit',
                     help="how match_cost carries out ApproxMatch -> MatchCost / MatchCostGrad (losses.MatchCostFunction.mode): "
@@ -379,7 +380,7 @@ def main() -> int:
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if launched:  # one process per GPU over RCCL (backend "nccl" on ROCm), also at world size 1
+    if launched and not args.no_dist_init:  # one process per GPU over RCCL (backend "nccl" on ROCm), also at world size 1
         import torch.distributed as dist_mod
 
         dist = dist_mod

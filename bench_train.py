@@ -2,7 +2,7 @@
 """End-to-end harness benchmarks for BASELINE configs[3] and configs[4].
 
   python bench_train.py --mode train --gpus N --steps K --warmup W   autoencoder training step, B=32 per GPU
-  python bench_train.py --mode infer --gpus N ...                    encoder -> classifier -> decoder + Chamfer/EMD metric
+  python bench_train.py --mode infer --gpus N ...                    classifier -> counterfactual (encoder, w-AE, codes, decoder) -> classifier + metric
 
 N>1: launch with ``python -m torch.distributed.run --nproc-per-node N ... bench_train.py --gpus N``; one rank per
 GPU, gradients averaged by DDP over RCCL (training) / no collective at all (inference).  Prints one JSON line on
@@ -52,13 +52,14 @@ def main() -> None:
         dist.init_process_group('nccl', device_id=dev)
 
     from pointcloudcounterfactual_amd import harness
-    from pointcloudcounterfactual_amd.losses import chamfer, match_cost
+    from pointcloudcounterfactual_amd.losses import chamfer_emd
     from tests.util import pair
 
     torch.manual_seed(1234 + 4 + rank)
     _, ref = pair(1234 + 4 + 1000 * rank, args.batch_per_gpu, args.points, args.points, 'recon')
     ref_t = torch.from_numpy(ref).to(dev)
-    model = harness.VQAutoencoder(n_points=args.points, fused=not args.unfused).to(dev)
+    model_cls = harness.VQAutoencoder if args.mode == 'train' else harness.CounterfactualVQVAE
+    model = model_cls(n_points=args.points, fused=not args.unfused).to(dev)
     clf = harness.DGCNNClassifier().to(dev)
     if args.mode == 'train':
         model.train()
@@ -78,10 +79,14 @@ def main() -> None:
 
         @torch.inference_mode()
         def step() -> None:
+            # evaluate_counterfactuals.py:61-88: classifier logits of the input -> counterfactual towards a target class
+            # (encoder -> w-autoencoder latent step -> nearest codes -> decoder) -> classifier on the result + the
+            # Chamfer / EMD metric between input and counterfactual
             logits = clf(ref_t)
-            out = model(ref_t)
-            _metric = chamfer(out['recon'], ref_t) + match_cost(out['recon'], ref_t)
-            _pred = clf(out['recon']).argmax(1) == logits.argmax(1)
+            out = model.generate_counterfactual(ref_t, logits, target_dim=3, target_value=1.0)
+            cham, emd = chamfer_emd(out['recon'], ref_t)
+            _metric = cham + emd
+            _flipped = clf(out['recon']).argmax(1) == 3
 
     def sync() -> None:
         torch.cuda.synchronize()
@@ -119,7 +124,7 @@ def main() -> None:
         print(json.dumps({
             'metric': 'clouds/sec ' + ('autoencoder train step (DGCNN enc + PCGen dec + Chamfer + EMD + AdamW)'
                                        if args.mode == 'train' else
-                                       'inference pipeline (classifier + encoder + decoder + Chamfer/EMD metric)'),
+                                       'counterfactual inference step (classifier + encoder + w-autoencoder + nearest codes + decoder + classifier + Chamfer/EMD metric)'),
             'value': args.batch_per_gpu * world * args.steps / el, 'unit': 'clouds/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': el / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

@@ -2113,32 +2113,19 @@ int launch_phase(const PhaseArgs &a, int b, int var, hipStream_t st, const char 
     }
 }
 
-struct StreamBuf {  // stream-ordered scratch (hipMallocAsync / hipFreeAsync)
+struct StreamBuf {  // stream-ordered scratch from the library's private pool (pcc::ws_malloc / ws_free)
     void *p = nullptr;
     hipStream_t st;
     explicit StreamBuf(hipStream_t s) : st(s) {}
     int alloc(size_t bytes) {
-        static bool pool_tuned = [] {
-            int dev = 0;
-            hipMemPool_t pool;
-            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-                uint64_t keep = ~0ull;  // keep freed blocks cached in the pool between calls
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-            }
-            return true;
-        }();
-        (void)pool_tuned;
-        hipError_t e = hipMallocAsync(&p, bytes, st);
-        if (e != hipSuccess) {
-            p = nullptr;
-            (void)hipGetLastError();
-            pcc::set_error(PCC_ENOMEM, "workspace hipMallocAsync failed");
+        if (pcc::ws_malloc(&p, bytes, st) != hipSuccess) {
+            pcc::set_error(PCC_ENOMEM, "workspace allocation failed");
             return PCC_ENOMEM;
         }
         return PCC_OK;
     }
     ~StreamBuf() {
-        if (p) (void)hipFreeAsync(p, st);
+        if (p) (void)pcc::ws_free(p, st);
     }
 };
 
@@ -2230,9 +2217,24 @@ hipStream_t side_stream(int which) {  // which = 0 .. kMaxLanes - 2
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || which < 0 || which >= kMaxLanes - 1) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
-    if (!streams[dev][which] && hipStreamCreateWithFlags(&streams[dev][which], hipStreamNonBlocking) != hipSuccess) {
-        streams[dev][which] = nullptr;
-        (void)hipGetLastError();
+    if (!streams[dev][which]) {
+        // HIP multiplexes the streams of a process onto a few hardware queues per PRIORITY class, in creation order: a
+        // plain side stream created after an application has made many streams of its own (RCCL does, at
+        // init_process_group) can land on the hardware queue of the caller's stream, and the two lanes then serialise
+        // (measured: 0.53 -> 0.73 ms per bench step).  A high-priority stream comes from a different queue pool than the
+        // caller's normal-priority stream.
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            least = greatest = 0;
+        }
+        if (hipStreamCreateWithPriority(&streams[dev][which], hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipStreamCreateWithFlags(&streams[dev][which], hipStreamNonBlocking) != hipSuccess) {
+                streams[dev][which] = nullptr;
+                (void)hipGetLastError();
+            }
+        }
     }
     return streams[dev][which];
 }

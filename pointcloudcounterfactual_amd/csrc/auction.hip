@@ -410,9 +410,9 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
             const size_t sync_words = 1 + (size_t)b * (2 + iters);
             const size_t bytes = (size_t)b * 4 * n * 4 + sync_words * 4;
             char *ws = nullptr;
-            if (hipMallocAsync(reinterpret_cast<void **>(&ws), bytes, st) != hipSuccess) {
+            if (pcc::ws_malloc(reinterpret_cast<void **>(&ws), bytes, st) != hipSuccess) {
                 (void)hipGetLastError();
-                pcc::set_error(PCC_ENOMEM, "auction: workspace hipMallocAsync failed");
+                pcc::set_error(PCC_ENOMEM, "auction: workspace allocation failed");
                 return PCC_ENOMEM;
             }
             int *scratch = reinterpret_cast<int *>(ws);
@@ -443,7 +443,7 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
                 ClusterState *cs = cluster_state();
                 if (cs && cs->last && hipEventRecord(cs->last, st) == hipSuccess) cs->last_stream = st;
             }
-            (void)hipFreeAsync(ws, st);
+            (void)pcc::ws_free(ws, st);
             return pcc::check_launch("auction_forward(cluster)");
         }
     }
@@ -456,9 +456,9 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
     }();
     (void)attr_done;
     int *scratch = nullptr;
-    if (!in_lds && hipMallocAsync(reinterpret_cast<void **>(&scratch), (size_t)b * state, st) != hipSuccess) {
+    if (!in_lds && pcc::ws_malloc(reinterpret_cast<void **>(&scratch), (size_t)b * state, st) != hipSuccess) {
         (void)hipGetLastError();
-        pcc::set_error(PCC_ENOMEM, "auction: workspace hipMallocAsync failed");
+        pcc::set_error(PCC_ENOMEM, "auction: workspace allocation failed");
         return PCC_ENOMEM;
     }
     {
@@ -466,7 +466,7 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
         hipLaunchKernelGGL(auction_kernel, dim3(b), dim3(1024), lds, st, n, xyz1, xyz2, eps, iters, dist, assignment,
                            scratch, in_lds);
     }
-    if (scratch) (void)hipFreeAsync(scratch, st);
+    if (scratch) (void)pcc::ws_free(scratch, st);
     return pcc::check_launch("auction_forward");
 }
 

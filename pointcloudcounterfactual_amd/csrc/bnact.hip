@@ -231,9 +231,9 @@ int pcc_bn_stats(int b, int c, int n, const float *z, float *mean, float *var, p
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int splits = pick_splits(b, c);
     double *part = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)c * splits * 2 * sizeof(double), st) != hipSuccess) {
+    if (pcc::ws_malloc(reinterpret_cast<void **>(&part), (size_t)c * splits * 2 * sizeof(double), st) != hipSuccess) {
         (void)hipGetLastError();
-        pcc::set_error(PCC_ENOMEM, "bn_stats: workspace hipMallocAsync failed");
+        pcc::set_error(PCC_ENOMEM, "bn_stats: workspace allocation failed");
         return PCC_ENOMEM;
     }
     {
@@ -242,7 +242,7 @@ int pcc_bn_stats(int b, int c, int n, const float *z, float *mean, float *var, p
     }
     hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(pcc::ceil_div(c, 256)), dim3(256), 0, st, c, splits, (double)b * n, part,
                        mean, var);
-    (void)hipFreeAsync(part, st);
+    (void)pcc::ws_free(part, st);
     return pcc::check_launch("bn_stats");
 }
 
@@ -274,9 +274,9 @@ int pcc_bn_relu_bwd(int b, int c, int n, const float *z, const float *mean, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int splits = pick_splits(b, c);
     double *part = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)c * splits * 2 * sizeof(double), st) != hipSuccess) {
+    if (pcc::ws_malloc(reinterpret_cast<void **>(&part), (size_t)c * splits * 2 * sizeof(double), st) != hipSuccess) {
         (void)hipGetLastError();
-        pcc::set_error(PCC_ENOMEM, "bn_relu_bwd: workspace hipMallocAsync failed");
+        pcc::set_error(PCC_ENOMEM, "bn_relu_bwd: workspace allocation failed");
         return PCC_ENOMEM;
     }
     {
@@ -286,7 +286,7 @@ int pcc_bn_relu_bwd(int b, int c, int n, const float *z, const float *mean, cons
     }
     hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(pcc::ceil_div(c, 256)), dim3(256), 0, st, c, splits, 1.0, part, grad_beta,
                        grad_gamma);
-    (void)hipFreeAsync(part, st);
+    (void)pcc::ws_free(part, st);
     {
         pcc::ProfScope prof("bn_relu_bwd_apply_kernel", st);
         const float inv_count = 1.0f / ((float)b * (float)n);

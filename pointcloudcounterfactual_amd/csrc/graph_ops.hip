@@ -467,9 +467,9 @@ int pcc_neighbour_sum_bwd(int b, int c, int n, int k, const int64_t *indices, co
     // sorted-edge schedule: needs 16-bit point ids and rows + bins of >= 1 channel in LDS
     if (sorted_enabled && n <= 65536 && (size_t)n * 8 <= 128 * 1024 && (size_t)n * 4 <= 160 * 1024 - 256) {
         unsigned *rev = nullptr;
-        if (hipMallocAsync(reinterpret_cast<void **>(&rev), (size_t)b * n * k * sizeof(unsigned), st) != hipSuccess) {
+        if (pcc::ws_malloc(reinterpret_cast<void **>(&rev), (size_t)b * n * k * sizeof(unsigned), st) != hipSuccess) {
             (void)hipGetLastError();
-            pcc::set_error(PCC_ENOMEM, "neighbour_sum_bwd: workspace hipMallocAsync failed");
+            pcc::set_error(PCC_ENOMEM, "neighbour_sum_bwd: workspace allocation failed");
             return PCC_ENOMEM;
         }
         static bool attr_sort = [] {
@@ -497,7 +497,7 @@ int pcc_neighbour_sum_bwd(int b, int c, int n, int k, const int64_t *indices, co
             }
 #undef PCC_LAUNCH_S
         }
-        (void)hipFreeAsync(rev, st);
+        (void)pcc::ws_free(rev, st);
         return pcc::check_launch("neighbour_sum_bwd(sorted)");
     }
     return scatter_bwd<3>(b, c, n, k, indices, nullptr, grad_out, grad_x, st, "scatter_lds_kernel<nbrsum>");

@@ -328,7 +328,7 @@ struct SqBuf {
     hipStream_t st;
     explicit SqBuf(hipStream_t s) : st(s) {}
     ~SqBuf() {
-        if (p) (void)hipFreeAsync(p, st);
+        if (p) (void)pcc::ws_free(p, st);
     }
 };
 
@@ -354,10 +354,10 @@ extern "C" int pcc_knn(int b, int c, int n, int k, const float *x, int64_t *indi
         return pcc::check_launch("knn(small)");
     }
     SqBuf sq(st);
-    if (hipMallocAsync(reinterpret_cast<void **>(&sq.p), (size_t)b * n * sizeof(float), st) != hipSuccess) {
+    if (pcc::ws_malloc(reinterpret_cast<void **>(&sq.p), (size_t)b * n * sizeof(float), st) != hipSuccess) {
         sq.p = nullptr;
         (void)hipGetLastError();
-        pcc::set_error(PCC_ENOMEM, "knn: workspace hipMallocAsync failed");
+        pcc::set_error(PCC_ENOMEM, "knn: workspace allocation failed");
         return PCC_ENOMEM;
     }
     hipLaunchKernelGGL(sqnorm_kernel, dim3(pcc::ceil_div(n, 256), b), dim3(256), 0, st, c, n, x, sq.p);

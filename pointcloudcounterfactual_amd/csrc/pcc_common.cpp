@@ -38,6 +38,45 @@ void prof_clear() {
 }
 }  // namespace
 
+namespace {
+std::mutex g_pool_mu;
+hipMemPool_t g_pools[64] = {};
+bool g_pool_failed[64] = {};
+hipMemPool_t device_pool() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (!g_pools[dev] && !g_pool_failed[dev]) {
+        hipMemPoolProps props{};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t pool = nullptr;
+        if (hipMemPoolCreate(&pool, &props) == hipSuccess) {
+            uint64_t keep = kPoolKeepBytes;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            g_pools[dev] = pool;
+        } else {
+            (void)hipGetLastError();
+            g_pool_failed[dev] = true;  // fall back to the default pool, untouched
+        }
+    }
+    return g_pools[dev];
+}
+}  // namespace
+
+hipError_t ws_malloc(void **p, size_t bytes, hipStream_t st) {
+    hipMemPool_t pool = device_pool();
+    hipError_t e = pool ? hipMallocFromPoolAsync(p, bytes, pool, st) : hipMallocAsync(p, bytes, st);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        (void)hipGetLastError();
+    }
+    return e;
+}
+hipError_t ws_free(void *p, hipStream_t st) { return p ? hipFreeAsync(p, st) : hipSuccess; }
+
 bool profiling() { return g_prof_mode != 0; }
 ProfScope::ProfScope(const char *kernel, hipStream_t s, bool coarse, bool enabled) : st(s), name(kernel) {
     if (!enabled || g_prof_mode != (coarse ? 2 : 1)) return;

@@ -51,4 +51,11 @@ struct ProfScope {
 
 __host__ __device__ constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Stream-ordered workspace of the library: one PRIVATE memory pool per device (hipMemPoolCreate), so that nothing is
+// configured on the device's default pool, which belongs to the application (PyTorch, RCCL ...).  Freed blocks stay
+// cached in the pool up to kPoolKeepBytes between calls; more than that is handed back at the next synchronisation.
+constexpr unsigned long long kPoolKeepBytes = 1ull << 30;
+hipError_t ws_malloc(void **p, size_t bytes, hipStream_t st);
+hipError_t ws_free(void *p, hipStream_t st);
+
 }  // namespace pcc

@@ -13,9 +13,13 @@ hot-path kernels in place.  Shapes follow the reference's source text:
             graph_filtering k=4 (src/module/decoders.py:39-130, configs/.../pcgen.yaml)
   loss      mean-Chamfer + match_cost + 8 * MSE(w_q, w_e)   (src/train/metrics_and_losses.py:21-90,258-266)
   optimiser AdamW lr 4e-3, weight decay 1e-3                (configs/.../learn/default_learn.yaml)
-The dense layers are plain PyTorch-ROCm modules (rocBLAS / MIOpen); every kNN, gather, max-pool, Chamfer and EMD
-call goes through this package's HIP kernels.  The w-autoencoder transformer of the reference's counterfactual
-path (src/module/w_autoencoders.py) is out of scope and is not modelled.
+  w-AE      counterfactual latent step (src/module/w_autoencoders.py:247-262, w_encoders.py:73-107, w_conditional.py:
+            15-102, w_decoders.py:71-112; configs/.../w_autoencoder/model/*.yaml): transformer encoder 4 -> 512 (2 layers,
+            8 heads, ff 1024, GELU, norm-first) -> z1 (16); conditional prior Linear(40 -> 256*32) and posterior
+            transformer (2 layers) on the interpolated class probabilities -> z2 (16); transformer decoder (4 layers,
+            ff 1024/1024/1024/512) -> w_recon; nearest code in the codebook -> indices -> embeddings -> PCGen.
+The dense layers (convolutions, transformers) are plain PyTorch-ROCm modules (rocBLAS / MIOpen / SDPA); every kNN,
+gather, max-pool, nearest-code search, Chamfer and EMD call goes through this package's HIP kernels.
 """
 
 from __future__ import annotations
@@ -29,7 +33,8 @@ from torch import nn
 from pointcloudcounterfactual_amd import _lib
 from pointcloudcounterfactual_amd import neighbour_ops as ops
 from pointcloudcounterfactual_amd.edgeconv import FusedEdgeConv
-from pointcloudcounterfactual_amd.losses import chamfer, match_cost
+from pointcloudcounterfactual_amd.keops_shim import SquareDistance
+from pointcloudcounterfactual_amd.losses import chamfer_emd
 
 
 class EdgeConv(nn.Module):
@@ -156,12 +161,22 @@ class DGCNNEncoder(nn.Module):
             layers += [EdgeConv(2 * cin, cout) for cin, cout in itertools.pairwise(self.h_dim)]
         self.edge_convolutions = nn.ModuleList(layers)
         self.final_conv = PointsConv(sum(self.h_dim), w_dim, bn=False)
+        # test hooks: the kNN graphs of a forward pass can be recorded, and replayed into another composition of the same
+        # layers (the dynamic graphs of layers 2-4 are built on features; two compositions that agree to rounding may
+        # still break a near tie differently, which the comparison must not mix up with a wrong layer)
+        self.recorded_graphs: list[torch.Tensor] | None = None
+        self.replay_graphs: list[torch.Tensor] | None = None
 
     def features(self, cloud: torch.Tensor) -> torch.Tensor:
         x = cloud.transpose(2, 1).contiguous()
         xs = []
-        for conv in self.edge_convolutions:
-            idx = ops.knn(x, self.k)  # dynamic graph every layer
+        for layer, conv in enumerate(self.edge_convolutions):
+            if self.replay_graphs is not None:
+                idx = self.replay_graphs[layer]
+            else:
+                idx = ops.knn(x, self.k)  # dynamic graph every layer
+            if self.recorded_graphs is not None:
+                self.recorded_graphs.append(idx)
             if self.fused:
                 x = conv(x, idx)
             else:
@@ -241,12 +256,7 @@ class VQAutoencoder(nn.Module):
         self.codebook = nn.Parameter(torch.randn(n_codes, book_size, dim))
 
     def quantize(self, w_q: torch.Tensor) -> torch.Tensor:
-        b = w_q.shape[0]
-        x = w_q.view(b, self.n_codes, 1, self.dim)
-        dist = ((x - self.codebook.unsqueeze(0)) ** 2).sum(-1)             # [B, codes, book]
-        idx = dist.argmin(2)
-        return torch.gather(self.codebook.unsqueeze(0).expand(b, -1, -1, -1), 2,
-                            idx[..., None, None].expand(-1, -1, 1, self.dim)).reshape(b, -1)
+        return decode_from_indices(quantize_indices(w_q.detach(), self.codebook.detach()), self.codebook)
 
     def forward(self, cloud: torch.Tensor) -> dict[str, torch.Tensor]:
         w_q = self.encoder(cloud)
@@ -256,10 +266,130 @@ class VQAutoencoder(nn.Module):
         return {'recon': recon, 'w_q': w_q, 'w_e': w_e}
 
 
+def quantize_indices(x: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
+    """``VectorQuantizer.quantize`` (src/module/quantize.py:20-32), index part: nearest entry of each of the ``n_codes``
+    books for ``x[B, n_codes * dim]`` -> ``idx[B, n_codes]``.  On the GPU the search runs on the HIP kernel behind the
+    PyKeOps call site of the reference (``pykeops_square_distance(x_flat, book_repeated).argmin(axis=2)``)."""
+    n_codes, book, dim = codebook.shape
+    b = x.shape[0]
+    x_flat = x.reshape(b * n_codes, 1, dim).contiguous()
+    book_repeated = codebook.repeat(b, 1, 1)
+    if x.is_cuda:
+        idx_flat = SquareDistance(x_flat, book_repeated).argmin(axis=2)
+    else:
+        idx_flat = ((x_flat[:, :, None, :] - book_repeated[:, None, :, :]) ** 2).sum(-1).argmin(2, keepdim=True)
+    return idx_flat.view(b, n_codes)
+
+
+def decode_from_indices(idx: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
+    """``VectorQuantizer.decode_from_indices`` (quantize.py:45-53): ``idx[B, n_codes]`` -> ``w[B, n_codes * dim]``."""
+    n_codes, _book, dim = codebook.shape
+    b = idx.shape[0]
+    book = codebook.repeat(b, 1, 1)
+    return book.gather(1, idx.reshape(b * n_codes, 1, 1).expand(-1, -1, dim)).view(b, n_codes * dim)
+
+
+class CounterfactualWAutoEncoder(nn.Module):
+    """The latent step of the reference's counterfactual generation, ``CounterfactualWAutoEncoder.generate_counterfactual``
+    (src/module/w_autoencoders.py:247-262) with the transformer encoder / conditional encoder / decoder of the default
+    configuration (wae.yaml).  Dense PyTorch; what it hands to the hot path is ``w_recon`` for the nearest-code search."""
+
+    def __init__(self, n_codes: int = 256, dim: int = 4, n_classes: int = 40, z1_dim: int = 16, z2_dim: int = 16,
+                 proj_dim: int = 512, n_heads: int = 8, cf_temperature: float = 5.0) -> None:
+        super().__init__()
+        self.n_codes, self.dim, self.n_classes, self.z1_dim, self.z2_dim = n_codes, dim, n_classes, z1_dim, z2_dim
+        self.temperature = cf_temperature
+
+        def enc_layer(ff: int, drop: float) -> nn.Module:
+            return nn.TransformerEncoderLayer(d_model=proj_dim, nhead=n_heads, dim_feedforward=ff, dropout=drop,
+                                              activation=nn.GELU(), batch_first=True, norm_first=True)
+
+        # TransformerWEncoder (w_encoders.py:73-107)
+        self.enc_proj = nn.Linear(dim, proj_dim)
+        self.enc_pos = nn.Parameter(torch.randn(1, n_codes, proj_dim))
+        self.enc_layers = nn.ModuleList([enc_layer(1024, 0.0), enc_layer(1024, 0.0)])
+        self.enc_latent = nn.Linear(proj_dim, 2 * z1_dim)
+        # ConditionalPrior + TransformerWConditionalEncoder (w_conditional.py:15-102)
+        self.prior = nn.Linear(n_classes, n_codes * 2 * z2_dim)
+        self.post_proj = nn.Linear(dim, proj_dim)
+        self.post_pos = nn.Parameter(torch.randn(1, n_codes, proj_dim))
+        self.post_prob = nn.Linear(n_classes, proj_dim)
+        self.post_layers = nn.ModuleList([enc_layer(1024, 0.0), enc_layer(1024, 0.0)])
+        self.post_latent = nn.Linear(proj_dim, 2 * z2_dim)
+        # TransformerWDecoder (w_decoders.py:71-112)
+        self.z1_proj = nn.Linear(z1_dim, proj_dim)
+        self.z2_proj = nn.Linear(z2_dim, proj_dim)
+        self.dec_pos = nn.Parameter(torch.randn(1, n_codes, proj_dim))
+        self.dec_mem_pos = nn.Parameter(torch.randn(1, n_codes, proj_dim))
+        self.dec_layers = nn.ModuleList([
+            nn.TransformerDecoderLayer(d_model=proj_dim, nhead=n_heads, dim_feedforward=ff, dropout=0.1,
+                                       activation=nn.GELU(), batch_first=True, norm_first=True)
+            for ff in (1024, 1024, 1024, 512)])
+        self.compress = nn.Linear(proj_dim, dim)
+
+    def encode_z1(self, x: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        h = self.enc_pos + self.enc_proj(x)
+        for layer in self.enc_layers:
+            h = layer(h)
+        mu, log_var = self.enc_latent(h).chunk(2, 2)
+        return mu, log_var
+
+    def posterior(self, probs: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        h = self.post_pos + self.post_proj(x) + self.post_prob(probs).unsqueeze(1)
+        for layer in self.post_layers:
+            h = layer(h)
+        return self.post_latent(h)
+
+    def decode(self, z1: torch.Tensor, z2: torch.Tensor) -> torch.Tensor:
+        b = z1.shape[0]
+        memory = self.z1_proj(z1) + self.dec_mem_pos
+        h = self.z2_proj(z2) + self.dec_pos
+        for layer in self.dec_layers:
+            h = layer(h, memory)
+        return self.compress(h).reshape(b, self.n_codes * self.dim)
+
+    def interpolated_probs(self, logits: torch.Tensor, target_dim: int, target_value: float) -> torch.Tensor:
+        old = torch.softmax(logits / self.temperature, dim=1)             # TemperatureScaledSoftmax, cf_temperature 5
+        target = torch.zeros_like(old)
+        target[:, target_dim] = 1
+        return (1 - target_value) * old + target_value * target           # interpolate_probs, :281-284
+
+    def counterfactual_w(self, w_q: torch.Tensor, logits: torch.Tensor, target_dim: int,
+                         target_value: float = 1.0) -> tuple[torch.Tensor, torch.Tensor]:
+        """-> (w_recon[B, n_codes * dim], probs[B, n_classes]): no sampling (z1 = mu1, z2 = p_mu2 + d_mu2, :258-260)."""
+        x = w_q.view(-1, self.n_codes, self.dim)
+        mu1, _ = self.encode_z1(x)
+        probs = self.interpolated_probs(logits, target_dim, target_value)
+        p_mu2, _ = self.prior(probs).view(-1, self.n_codes, 2 * self.z2_dim).chunk(2, 2)
+        d_mu2, _ = self.posterior(probs, x).chunk(2, 2)
+        return self.decode(mu1, p_mu2 + d_mu2), probs
+
+
+class CounterfactualVQVAE(VQAutoencoder):
+    """``CounterfactualVQVAE.generate_counterfactual`` (src/module/autoencoders.py:168-181): encoder -> w-autoencoder
+    latent step on the classifier's logits -> nearest codes -> embeddings -> decoder, one forward pass."""
+
+    def __init__(self, n_points: int = 2048, k: int = 25, n_codes: int = 256, book_size: int = 16, dim: int = 4,
+                 n_classes: int = 40, fused: bool = True) -> None:
+        super().__init__(n_points=n_points, k=k, n_codes=n_codes, book_size=book_size, dim=dim, fused=fused)
+        self.w_autoencoder = CounterfactualWAutoEncoder(n_codes=n_codes, dim=dim, n_classes=n_classes)
+
+    @torch.inference_mode()
+    def generate_counterfactual(self, cloud: torch.Tensor, sample_logits: torch.Tensor, target_dim: int,
+                                target_value: float = 1.0) -> dict[str, torch.Tensor]:
+        w_q = self.encoder(cloud)
+        w_recon, probs = self.w_autoencoder.counterfactual_w(w_q, sample_logits, target_dim, target_value)
+        idx = quantize_indices(w_recon, self.codebook)
+        w = decode_from_indices(idx, self.codebook)
+        recon = self.decoder(w, self.n_points).transpose(2, 1).contiguous()
+        return {'recon': recon, 'w_q': w_q, 'w_recon': w_recon, 'idx': idx, 'w': w, 'probs': probs}
+
+
 def autoencoder_loss(out: dict[str, torch.Tensor], ref: torch.Tensor, c_embedding: float = 8.0) -> torch.Tensor:
     """Per-sample loss [B]: mean-Chamfer + approximate EMD + c * MSE(w_q, w_e) (chamfer_emd.yaml)."""
     embed = F.mse_loss(out['w_q'], out['w_e'], reduction='none').mean(dim=1)
-    return chamfer(out['recon'], ref) + match_cost(out['recon'], ref) + c_embedding * embed
+    cham, emd = chamfer_emd(out['recon'], ref)  # the reference's ChamferEMD loss as one autograd node
+    return cham + emd + c_embedding * embed
 
 
 def make_optimizer(model: nn.Module) -> torch.optim.Optimizer:

@@ -1,6 +1,7 @@
 """GPU smoke tests of the training / inference harness: shapes, finite loss, gradients reach every
 trainable parameter, one optimiser step changes the loss, inference pipeline runs under inference_mode."""
 
+import numpy as np
 import pytest
 import torch
 
@@ -78,3 +79,119 @@ def test_points_conv_fused_tail_matches_torch(cuda, cin, cout, residual, n, trai
     torch.testing.assert_close(fused.bn.running_mean, plain.bn.running_mean, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(fused.bn.running_var, plain.bn.running_var, rtol=1e-5, atol=1e-6)
     assert int(fused.bn.num_batches_tracked) == int(plain.bn.num_batches_tracked)
+
+
+def _clone_into(dst, src):
+    """Same parameters and buffers in both models (FusedEdgeConv keeps the unfused block's Conv2d + BatchNorm2d)."""
+    missing = dst.load_state_dict(src.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+
+
+def test_train_step_at_config4_workload_fused_equals_unfused(cuda):
+    """BASELINE configs[3] at its per-GPU workload (B=32, N=2048, k=25): one training step of the harness with the fused
+    EdgeConv front-end against the same step composed as the reference composes it ([B,2C,N,k] edge tensors): same
+    weights, same random draws (seed re-set before each forward: decoder sample + gumbel noise) and the same kNN graphs
+    (recorded from the reference composition, replayed into the fused one -- the dynamic graphs of layers 2-4 are built
+    on features, and two compositions that agree to rounding may still break a near tie differently).  Per-sample
+    losses and every parameter gradient must agree.  The free-running fused step (its own graphs) is reported and held
+    to a loose bound: that difference is the sensitivity of a randomly initialised network to its neighbour choices,
+    not an error of a kernel."""
+    from pointcloudcounterfactual_amd import harness
+
+    _, ref = pair(1234 + 4, 32, 2048, 2048)
+    ref_t = torch.from_numpy(ref).to(cuda)
+    torch.manual_seed(11)
+    unfused = harness.VQAutoencoder(n_points=2048, k=25, fused=False).to(cuda).train()
+    fused = harness.VQAutoencoder(n_points=2048, k=25, fused=True).to(cuda).train()
+    free = harness.VQAutoencoder(n_points=2048, k=25, fused=True).to(cuda).train()
+    _clone_into(fused, unfused)
+    _clone_into(free, unfused)
+    unfused.encoder.recorded_graphs = []
+    res = {}
+    for name, model in (('unfused', unfused), ('fused', fused), ('free', free)):
+        if name == 'fused':
+            model.encoder.replay_graphs = unfused.encoder.recorded_graphs
+        torch.manual_seed(99)
+        out = model(ref_t)
+        assert out['recon'].shape == (32, 2048, 3)
+        loss = harness.autoencoder_loss(out, ref_t)
+        assert loss.shape == (32,) and torch.isfinite(loss).all()
+        loss.mean().backward()
+        res[name] = (loss.detach(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+        torch.cuda.synchronize()
+    assert len(unfused.encoder.recorded_graphs) == 4
+    lu, lf = res['unfused'][0], res['fused'][0]
+    rel = ((lu - lf).abs() / lu.abs()).max().item()
+    gu, gf = res['unfused'][1], res['fused'][1]
+    assert gu.keys() == gf.keys()
+    worst = 1.0
+    for n in gu:
+        a, b = gu[n].flatten().double(), gf[n].flatten().double()
+        if a.numel() < 64 or a.norm() == 0:
+            continue
+        worst = min(worst, float(torch.dot(a, b) / (a.norm() * b.norm())))
+    rel_free = ((lu - res['free'][0]).abs() / lu.abs()).max().item()
+    print(f'config-4 step, same graphs: loss rel diff {rel:.2e}, worst gradient cosine {worst:.6f}; own graphs: loss rel diff {rel_free:.2e}')
+    assert rel < 2e-3, rel
+    assert worst >= 0.999, worst
+    assert rel_free < 0.2, rel_free
+    # one optimiser step on the fused model moves the loss
+    opt = harness.make_optimizer(free)
+    opt.step()
+
+
+def test_counterfactual_step_at_config5_workload(cuda):
+    """BASELINE configs[4] at its per-GPU workload (B=32, N=2048): the reference's counterfactual step
+    (autoencoders.py:168-181, w_autoencoders.py:247-262, evaluate_counterfactuals.py:61-88) -- classifier logits ->
+    encoder -> w-autoencoder latent interpolation -> nearest codes (HIP search) -> embeddings -> decoder -> classifier
+    + Chamfer / EMD metric -- with the fused front-end against the unfused composition on the same weights, and the
+    nearest-code search against a dense float64 evaluation."""
+    from pointcloudcounterfactual_amd import harness
+    from pointcloudcounterfactual_amd.losses import chamfer_emd
+
+    _, ref = pair(1234 + 5, 32, 2048, 2048)
+    ref_t = torch.from_numpy(ref).to(cuda)
+    torch.manual_seed(5)
+    unfused = harness.CounterfactualVQVAE(n_points=2048, fused=False).to(cuda).eval()
+    fused = harness.CounterfactualVQVAE(n_points=2048, fused=True).to(cuda).eval()
+    _clone_into(fused, unfused)
+    clf = harness.DGCNNClassifier().to(cuda).eval()
+    outs = {}
+    with torch.inference_mode():
+        logits = clf(ref_t)
+        assert logits.shape == (32, 40)
+        unfused.encoder.recorded_graphs = []
+        for name, model in (('unfused', unfused), ('fused', fused)):
+            if name == 'fused':  # same kNN graphs in both compositions (see the config-4 test)
+                model.encoder.replay_graphs = unfused.encoder.recorded_graphs
+            torch.manual_seed(77)  # the decoder draws its sample points
+            out = model.generate_counterfactual(ref_t, logits, target_dim=3, target_value=1.0)
+            cham, emd = chamfer_emd(out['recon'], ref_t)
+            outs[name] = (out, cham, emd, clf(out['recon']))
+    out = outs['fused'][0]
+    assert out['recon'].shape == (32, 2048, 3) and out['idx'].shape == (32, 256)
+    assert int(out['idx'].min()) >= 0 and int(out['idx'].max()) < 16
+    np.testing.assert_allclose(out['probs'][:, 3].cpu().numpy(), 1.0)  # target_value 1: all mass on the target class
+    # nearest-code search (HIP) == dense float64 argmin over each book, outside float64-certified near ties
+    w = out['w_recon'].double().view(32, 256, 1, 4)
+    d = ((w - fused.codebook.double().unsqueeze(0)) ** 2).sum(-1)  # [B, codes, book]
+    dense = d.argmin(2)
+    diff = dense != out['idx']
+    if bool(diff.any()):
+        gap = (d.gather(2, out['idx'].unsqueeze(2)) - d.gather(2, dense.unsqueeze(2))).squeeze(2)[diff]
+        assert float(gap.max()) < 1e-6 * float(d.max())
+    with torch.inference_mode():
+        assert torch.equal(out['w'], harness.decode_from_indices(out['idx'], fused.codebook))
+    # fused front-end == reference composition of the encoder: same codes almost everywhere, same metric
+    same = float((outs['fused'][0]['idx'] == outs['unfused'][0]['idx']).float().mean())
+    assert same > 0.99, same
+    for k in (1, 2):
+        assert torch.isfinite(outs['fused'][k]).all()
+    if same == 1.0:
+        for k in (1, 2):
+            np.testing.assert_allclose(outs['fused'][k].cpu().numpy(), outs['unfused'][k].cpu().numpy(), rtol=1e-4)
+    # interpolation: target_value 0 keeps the classifier's own (temperature-scaled) probabilities
+    with torch.inference_mode():
+        p0 = fused.w_autoencoder.interpolated_probs(logits, 3, 0.0)
+    np.testing.assert_allclose(p0.cpu().numpy(), torch.softmax(logits / 5.0, 1).cpu().numpy(), rtol=1e-6)
+    print(f'config-5 step: identical codes {same:.4f}')
