@@ -289,7 +289,13 @@ __global__ __launch_bounds__(1024) void nbrsum_bwd_sorted_kernel(int c, int n, i
     }
 }
 
-// One wave per (b,c) row: max (first maximum), argmax and mean over n.
+// One wave per (b,c) row: max (first maximum), argmax and mean over n.  HBM-bound (the encoder's [B,1024,N] tensor is
+// 256 MiB at B=32, N=2048): rows are streamed with 16-byte non-temporal loads, eight in flight per lane before the first
+// use; a lane's indices only grow, so inside a lane the strict compare already keeps the first maximum and the index
+// tie-break is needed only when the lanes meet.
+typedef float gp_v4f __attribute__((ext_vector_type(4)));
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void global_pool_kernel(int rows, int n, const float *__restrict__ x,
                                                            float *__restrict__ out_max, int32_t *__restrict__ argmax,
                                                            float *__restrict__ out_mean) {
@@ -300,19 +306,48 @@ __global__ __launch_bounds__(256) void global_pool_kernel(int rows, int n, const
     float best = -__builtin_inff();
     int bi = 0x7fffffff;
     float sum = 0.f;
-    for (int i = lane; i < n; i += 64) {
-        const float v = r[i];
-        sum += v;
-        const bool gt = v > best || (v == best && i < bi);
-        best = gt ? v : best;
-        bi = gt ? i : bi;
+    if (VEC) {
+        constexpr int U = 8;
+        const gp_v4f *r4 = reinterpret_cast<const gp_v4f *>(r);
+        const int n4 = n >> 2;
+        for (int i0 = lane; i0 < n4; i0 += 64 * U) {
+            gp_v4f v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + 64 * u;
+                v[u] = i < n4 ? __builtin_nontemporal_load(r4 + i)
+                              : gp_v4f{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int i = i0 + 64 * u;
+                if (i < n4) sum += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+                const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    // NaN wins and sticks (torch.max propagates NaN): the first NaN of the lane is kept
+                    const bool gt = e[q] > best || (e[q] != e[q] && best == best);
+                    best = gt ? e[q] : best;
+                    bi = gt ? 4 * i + q : bi;
+                }
+            }
+        }
+    } else {
+        for (int i = lane; i < n; i += 64) {
+            const float v = r[i];
+            sum += v;
+            const bool gt = v > best || (v != v && best == best);
+            best = gt ? v : best;
+            bi = gt ? i : bi;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_down(best, off, 64);
         const int oi = __shfl_down(bi, off, 64);
         sum += __shfl_down(sum, off, 64);
-        const bool gt = ov > best || (ov == best && oi < bi);
+        const bool on = ov != ov, bn = best != best;
+        const bool gt = on ? (!bn || oi < bi) : (!bn && (ov > best || (ov == best && oi < bi)));
         best = gt ? ov : best;
         bi = gt ? oi : bi;
     }
@@ -523,8 +558,13 @@ int pcc_global_pool(int b, int c, int n, const float *x, float *out_max, int32_t
     const long long rows = (long long)b * c;
     if (rows > 0x7fffffffLL) return pcc::invalid("global_pool: too many rows");
     pcc::ProfScope prof("global_pool_kernel", st);
-    hipLaunchKernelGGL(global_pool_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (int)rows, n, x, out_max,
-                       argmax, out_mean);
+    const bool vec = n % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(global_pool_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (int)rows, n, x,
+                           out_max, argmax, out_mean);
+    else
+        hipLaunchKernelGGL(global_pool_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (int)rows, n, x,
+                           out_max, argmax, out_mean);
     return pcc::check_launch("global_pool");
 }
 
