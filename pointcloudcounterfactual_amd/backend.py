@@ -219,11 +219,13 @@ def ChamferLossGrad(set_d: torch.Tensor, set_q: torch.Tensor, idx1: torch.Tensor
     return [grad1, grad2]
 
 
-def ChamferEMD(set_d: torch.Tensor, set_q: torch.Tensor, mean: bool, with_grad: bool) -> list[torch.Tensor]:
+def ChamferEMD(set_d: torch.Tensor, set_q: torch.Tensor, mean: bool, with_grad: bool,
+               return_dist: bool = False) -> list[torch.Tensor]:
     """``ChamferLoss`` and ``MatchCostImplicit`` on the same pair of clouds in ONE call (extension, ``pcc_chamfer_emd``;
     the reference's ChamferEMD loss, metrics_and_losses.py:70-79) -> [chamfer[B], idx1, idx2, emd[B]] (+ [emd_grad1,
-    emd_grad2] ``with_grad``).  Same bits as the two calls; the nearest-neighbour search is scheduled by the library on
-    an internal stream in the shadow of the approximate EMD's late passes."""
+    emd_grad2] ``with_grad``) (+ [dist1, dist2] ``return_dist``).  Same bits as the two calls; the nearest-neighbour
+    search runs on the clouds the approximate EMD has just Hilbert-sorted, with box culling instead of the exhaustive
+    scan."""
     b, n, m = _sizes(set_d, set_q)
     dev = set_d.device
     _check_input(set_d, 'set_d')
@@ -247,6 +249,8 @@ def ChamferEMD(set_d: torch.Tensor, set_q: torch.Tensor, mean: bool, with_grad: 
                                       idx1.data_ptr(), d2.data_ptr(), idx2.data_ptr(), cost.data_ptr(),
                                       g1.data_ptr() if with_grad else None, g2.data_ptr() if with_grad else None,
                                       _stream(set_d)), 'ChamferEMD')
+    if return_dist:
+        out += [d1, d2]
     return out
 
 

@@ -940,6 +940,217 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Nearest neighbours on the sorted clouds (the Chamfer half of the reference's ChamferEMD loss, nndistance.cu:2-128, when
+// it is computed in the same call as the approximate EMD: pcc_chamfer_emd).  The exhaustive scan of nn_fwd_kernel
+// evaluates every pair; here the Hilbert-sorted points, the 16-point boxes and the permutations of THIS call's sort are
+// reused, and a group of 16 consecutive sorted queries only visits the candidate blocks that can still hold a nearest
+// neighbour:
+//   1. the candidate blocks of a window are ordered by the distance between their box and the group's box (a lower
+//      bound of every distance between the two boxes) and visited nearest first;
+//   2. the group's radius is the largest of its queries' best distances so far; the first block whose box is farther
+//      than the radius ends the walk (everything behind it is farther still): exact, nothing that could win -- or tie
+//      with a lower index -- is skipped.  On the bench clouds a group visits 11 of 128 blocks on average (43 at most);
+//   3. ties go to the lowest ORIGINAL candidate index (the reference's rule; the sorted order is not the original one):
+//      the best so far is one 64-bit key (distance bits : original index).  Distances are the oracle's fmaf chain:
+//      indices and distances carry the bits of nn_fwd_kernel / the oracle (tests/test_gpu_structural.py).
+// Measured: 42 us per half-batch launch at B=32, N=2048 -- on a par with the exhaustive kernel (the 16 x 16 tile steps cost
+// ~100 instructions each, 4x the exhaustive kernel's cost per pair, on 9 % of the pairs); what the fused call saves is
+// the separate loss-reduction launch (it rides in the finish launch) and the second read of the clouds.
+// ---------------------------------------------------------------------------------------------------
+struct NNSortedArgs {
+    int n_q, n_c, q_n4, c_n4, q_nb, c_nb, groups, batch;
+    const float *q_soa;            // [b][3][n4]
+    const float4 *c_aos;           // [b][n_c] (x, y, z, original index) per sorted candidate
+    const float *q_box, *c_box;    // [b][nb][8]
+    const int *q_perm;             // [b][n] sorted position -> original index
+    float *out_d;                  // [b][n_q] in the caller's query order
+    int *out_i;
+};
+
+// minimum over the 16 lanes of a DPP row, in every lane of the row: four cross-lane VALU operands (xor 1, xor 2, then the
+// two mirror steps) instead of four trips through the LDS crossbar (ds_bpermute)
+__device__ __forceinline__ float row_min16(float v) {
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true)));  // row_half_mirror
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true)));  // row_mirror
+    return v;
+}
+
+// A WAVE owns one group of 16 consecutive sorted queries and works alone (no LDS, no barrier: thousands of independent
+// waves hide each other's latency): lane = (candidate slot cl of a 16-candidate block, query quad), four queries in
+// registers.  128 candidate blocks per window: every lane tests two of them against the group's box, the survivors are
+// two 64-bit ballots that the wave walks bit by bit; a lane loads ITS candidate of the block straight from the sorted
+// rows (L2-resident), the next block's loads are issued before the current one is consumed.
+constexpr int kNNWaves = 4;  // independent waves per workgroup
+
+__global__ __launch_bounds__(64 * kNNWaves) void nn_sorted_kernel(NNSortedArgs a0, NNSortedArgs a1, int waves0) {
+    const int lane = threadIdx.x & 63;
+    int gw = (int)blockIdx.x * kNNWaves + (int)(threadIdx.x >> 6);   // global wave = (direction, sample, group)
+    const bool second = gw >= waves0;
+    const NNSortedArgs &a = second ? a1 : a0;
+    if (second) gw -= waves0;
+    const int smp = gw / a.groups;
+    const int grp = gw - smp * a.groups;
+    if (smp >= a.batch) return;  // (whole wave)
+    const int cl = lane & (kBox - 1), quad = lane / kBox;
+    const float *Q = a.q_soa + (size_t)smp * 3 * a.q_n4;
+    const float4 *C = a.c_aos + (size_t)smp * a.n_c;
+
+    // best so far per query as ONE 64-bit key (distance bits : original candidate index): squared distances are
+    // non-negative floats, which order like unsigned integers, so a single 64-bit compare is the reference's rule
+    // "smaller distance, lowest index on ties"
+    float qx[kFineQ], qy[kFineQ], qz[kFineQ];
+    unsigned long long bk[kFineQ];
+#pragma unroll
+    for (int j = 0; j < kFineQ; j++) {
+        int q = grp * kBox + quad * kFineQ + j;
+        q = q < a.n_q ? q : a.n_q - 1;
+        qx[j] = Q[q];
+        qy[j] = Q[a.q_n4 + q];
+        qz[j] = Q[2 * a.q_n4 + q];
+        bk[j] = ((unsigned long long)__float_as_uint(__builtin_inff()) << 32) | 0x7fffffffull;
+    }
+    const float4 *gb = reinterpret_cast<const float4 *>(a.q_box + ((size_t)smp * a.q_nb + grp) * 8);
+    const float4 glo = gb[0], ghi = gb[1];
+
+    struct Cand {
+        float x, y, z;
+        int o;
+    };
+    auto load_block = [&](int blk) -> Cand {  // this lane's candidate of block `blk` (+inf / INT_MAX beyond the cloud)
+        // unconditional loads of a clamped index (a branch around them would serialise the software pipeline below),
+        // then the select
+        const int ci = blk * kBox + cl;
+        const bool real = ci < a.n_c;
+        const unsigned cc = (unsigned)(real ? ci : a.n_c - 1);
+        const float4 v = C[cc];  // one 16-byte load per lane and block
+        Cand c;
+        c.x = real ? v.x : __builtin_inff();
+        c.y = v.y;
+        c.z = v.z;
+        c.o = real ? __float_as_int(v.w) : 0x7fffffff;
+        return c;
+    };
+    auto scan = [&](const Cand &c) {
+#pragma unroll
+        for (int j = 0; j < kFineQ; j++) {
+            const float d = sq3(c.x - qx[j], c.y - qy[j], c.z - qz[j]);
+            const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)c.o;
+            bk[j] = k < bk[j] ? k : bk[j];
+        }
+    };
+    // the group's radius: every query's best so far over its 16 candidate lanes, the largest over the 16 queries
+    auto group_radius = [&]() -> float {
+        float r = 0.f;
+#pragma unroll
+        for (int j = 0; j < kFineQ; j++) {
+            const float m = row_min16(__uint_as_float((unsigned)(bk[j] >> 32)));
+            r = fmaxf(r, grp * kBox + quad * kFineQ + j < a.n_q ? m : 0.f);
+        }
+        // the four rows (query quads) meet through scalar reads
+        const int ri = __float_as_int(r);
+        const float r0 = __int_as_float(__builtin_amdgcn_readlane(ri, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(ri, 16));
+        const float r2 = __int_as_float(__builtin_amdgcn_readlane(ri, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(ri, 48));
+        return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+    };
+
+    float r = __builtin_inff();  // the group's radius: the largest of its queries' best distances so far
+    for (int b0 = 0; b0 < a.c_nb; b0 += 128) {  // windows of 128 candidate blocks (2048 candidates)
+        // every lane: two blocks of the window, keyed by the lower bound of every distance between the group's box and
+        // the block's box.  key = lower bound with its 7 lowest mantissa bits replaced by the block's slot: positive
+        // floats order like unsigned integers, and the truncation only makes the bound smaller (conservative)
+        unsigned key[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int blk = b0 + lane + 64 * h;
+            key[h] = 0xffffffffu;
+            if (blk < a.c_nb) {
+                const float4 *cb = reinterpret_cast<const float4 *>(a.c_box + ((size_t)smp * a.c_nb + blk) * 8);
+                const float4 lo = cb[0], hi = cb[1];
+                const float dx = fmaxf(fmaxf(glo.x - hi.x, lo.x - ghi.x), 0.f);
+                const float dy = fmaxf(fmaxf(glo.y - hi.y, lo.y - ghi.y), 0.f);
+                const float dz = fmaxf(fmaxf(glo.z - hi.z, lo.z - ghi.z), 0.f);
+                key[h] = (__float_as_uint(dx * dx + dy * dy + dz * dz) & ~127u) | (unsigned)(lane + 64 * h);
+            }
+        }
+        // ascending bitonic sort of the 128 keys held by the wave (element lane + 64 h): nearest boxes first
+#pragma unroll
+        for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j == 64) {
+                    const unsigned mn = min(key[0], key[1]), mx = max(key[0], key[1]);
+                    key[0] = mn;
+                    key[1] = mx;
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int i = lane + 64 * h;
+                        const unsigned other = (unsigned)__shfl_xor((int)key[h], j, 64);
+                        const bool take_min = ((i & j) == 0) == ((i & k) == 0);
+                        key[h] = take_min ? min(key[h], other) : max(key[h], other);
+                    }
+                }
+            }
+        }
+        // walk the window nearest-first; a block farther than the radius ends it (everything behind is farther still):
+        // nothing that could win, or tie with a lower original index, is skipped.  Two blocks are in flight ahead.
+        // (branch-free: a branch around the look-ahead loads makes the compiler drain them before every use)
+        auto key_at = [&](int p) -> unsigned {
+            const int pl = __builtin_amdgcn_readfirstlane(p) & 63;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)key[0], pl);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)key[1], pl);
+            return p < 64 ? lo : hi;
+        };
+        const int nwin = min(128, a.c_nb - b0);
+        // batches of four blocks: their sixteen loads are issued together, each block is consumed as soon as ITS loads
+        // have landed (straight-line code: the compiler counts the outstanding loads exactly), the radius is refreshed
+        // after every batch
+        bool done = false;
+        for (int p = 0; p < nwin && !done; p += 4) {
+            unsigned kk[4];
+            Cand cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                kk[u] = key_at(min(p + u, nwin - 1));  // (past the end: the last block again, never consumed)
+                cc[u] = load_block(b0 + (int)(kk[u] & 127u));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!done) {
+                    if (p + u >= nwin || __uint_as_float(kk[u] & ~127u) > r) done = true;
+                    else scan(cc[u]);
+                }
+            }
+            r = fminf(r, group_radius());
+        }
+    }
+    // every query: best over its 16 candidate lanes
+#pragma unroll
+    for (int j = 0; j < kFineQ; j++) {
+#pragma unroll
+        for (int off = 1; off < kBox; off <<= 1) {
+            const unsigned hi = (unsigned)__shfl_xor((int)(bk[j] >> 32), off, 64);
+            const unsigned lo = (unsigned)__shfl_xor((int)(bk[j] & 0xffffffffu), off, 64);
+            const unsigned long long ok = ((unsigned long long)hi << 32) | lo;
+            bk[j] = ok < bk[j] ? ok : bk[j];
+        }
+    }
+    if (cl == 0) {
+#pragma unroll
+        for (int j = 0; j < kFineQ; j++) {
+            const int qs = grp * kBox + quad * kFineQ + j;
+            if (qs < a.n_q) {
+                const int orig = a.q_perm[(size_t)smp * a.n_q + qs];
+                a.out_d[(size_t)smp * a.n_q + orig] = __uint_as_float((unsigned)(bk[j] >> 32));
+                a.out_i[(size_t)smp * a.n_q + orig] = (int)(bk[j] & 0xffffffffu);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Persistent schedule (experimental, off by default -- see the measurement note at its launch site): ONE launch runs
 // all 19 passes.  The measured fixed cost of a pass launch (dispatch, prologue latency, drain) is 10.5 us -- a third
 // of the forward once the exact-zero work is skipped.  Here a workgroup keeps
@@ -1055,6 +1266,7 @@ struct SortArgs {  // one entry per cloud; blockIdx.y selects it
     float *soa[2];
     int *rank[2];
     int *perm[2];      // sorted position -> original index (inverse of rank)
+    float4 *aos[2];    // optional [b][n]: (x, y, z, original index as bits) per sorted point (nn_sorted_kernel)
     float *box[2];
     float *box64[2];
     int nb64[2];
@@ -1126,6 +1338,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     float *so = a.soa[which] + (size_t)smp * 3 * n4;
     int *rk = a.rank[which] + (size_t)smp * n;
     int *pm = a.perm[which] + (size_t)smp * n;
+    float4 *ao = a.aos[which] ? a.aos[which] + (size_t)smp * n : nullptr;
     float *bx = a.box[which] + (size_t)smp * nb * 8;
     float *bx64 = a.box64[which] + (size_t)smp * a.nb64[which] * 8;
     int idx_bits = 10;
@@ -1196,6 +1409,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
             z = p[orig * 3 + 2];
             rk[orig] = s;
             pm[s] = orig;
+            if (ao) ao[s] = make_float4(x, y, z, __int_as_float(orig));
         }
         if (s < n4) {
             so[s] = x;
@@ -1952,10 +2166,33 @@ struct FinishArgs {
     const int *perm[2];   // sorted position -> caller's point index
     const float *scale;
     float *out[3];
+    // the Chamfer half of a ChamferEMD call rides along (blockIdx.z == 3): loss[b] = sum / mean of the two distance rows
+    const float *ch_d1, *ch_d2;
+    float *ch_loss;
+    int ch_n, ch_m, ch_mean;
 };
 __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
     __shared__ float red[256];
     const int which = blockIdx.z, smp = blockIdx.y, tid = threadIdx.x;
+    if (which == 3) {  // the same fixed-order tree as chamfer_reduce_kernel (chamfer.hip): the same bits
+        if (blockIdx.x) return;
+        __shared__ float red2[256];
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = tid; i < f.ch_n; i += 256) s1 += f.ch_d1[(size_t)smp * f.ch_n + i];
+        for (int i = tid; i < f.ch_m; i += 256) s2 += f.ch_d2[(size_t)smp * f.ch_m + i];
+        red[tid] = s1;
+        red2[tid] = s2;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) {
+                red[tid] += red[tid + off];
+                red2[tid] += red2[tid + off];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) f.ch_loss[smp] = f.ch_mean ? red2[0] / (float)f.ch_m + red[0] / (float)f.ch_n : red[0] + red2[0];
+        return;
+    }
     if (which == 2) {  // cost[b] = sum of the workgroup partials, fixed order
         if (blockIdx.x) return;
         const int parts = f.parts[2];
@@ -2136,7 +2373,7 @@ size_t cost_parts(int n, int m) { return (size_t)pcc::ceil_div(n, kMatKT) * pcc:
 // Workspace carve (bytes, every section 16-byte aligned).
 struct WsLayout {
     int n4, m4, nb1, nb2, nb64_1, nb64_2;
-    size_t soa1, soa2, rank1, rank2, perm1, perm2, box1, box2, box64_1, box64_2, rem, lv, lv_orig, cpart, sync, clist, clist_cnt, live_cnt, total;
+    size_t soa1, soa2, rank1, rank2, perm1, perm2, box1, box2, box64_1, box64_2, rem, lv, lv_orig, cpart, sync, clist, clist_cnt, live_cnt, aos1, aos2, total;
     WsLayout(int b, int n, int m) {
         auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
         n4 = (n + 3) & ~3;
@@ -2164,15 +2401,18 @@ struct WsLayout {
         clist = o; o = up(o + (size_t)b * 5 * m4 * 4);   // dense candidate list handed from pass B to pass C/A
         clist_cnt = o; o = up(o + (size_t)b * 4);
         live_cnt = o; o = up(o + (size_t)b * kLiveRow * 4);
+        aos1 = o; o = up(o + (size_t)b * n * 16);   // packed sorted points for the nearest-neighbour search of pcc_chamfer_emd
+        aos2 = o; o = up(o + (size_t)b * m * 16);
         total = o;
     }
 };
 
 int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const float *xyz2, float *soa1, float *soa2,
                 int *rank1, int *rank2, int *perm1, int *perm2, float *box1, float *box2, float *box64_1, float *box64_2, float *rem, float *lv,
-                int *live_cnt, hipStream_t st) {
+                int *live_cnt, float4 *aos1, float4 *aos2, hipStream_t st) {
     SortArgs a{};
     a.live_cnt = live_cnt;
+    a.aos[0] = aos1; a.aos[1] = aos2;
     // the padded tails of the weight rows are staged as float4: they must be finite (their candidates sit at the
     // origin with these weights), and V_COWN relies on zero-filled level arrays for the exhausted owners it never
     // touches: remain rows are cleared by the workgroup sorting set1, level rows by the one sorting set2
@@ -2264,7 +2504,8 @@ struct ForkJoin {  // side waits for everything enqueued on main so far; at scop
 // Sort + the 19 passes: leaves the nine (ratioL | ratioR) level rows and remainL | remainR in the workspace, in the
 // Hilbert-sorted index space.
 int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const WsLayout &L, char *base, hipStream_t st,
-               bool *persist_out, const std::function<int(int, int, hipStream_t)> &lane_tail = nullptr) {
+               bool *persist_out, const std::function<int(int, int, hipStream_t)> &lane_tail = nullptr,
+               const std::function<int(int, int, hipStream_t)> &after_sort = nullptr) {
     const LevelConsts lc = make_levels();
     float multiL, multiR;  // approxmatch.cu:6-12 (integer division)
     if (n >= m) { multiL = 1; multiR = (float)(n / m); }
@@ -2393,7 +2634,11 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
                          reinterpret_cast<int *>(base + L.perm2) + s0 * m, const_cast<float *>(ln.sc.box1),
                          const_cast<float *>(ln.sc.box2), const_cast<float *>(ln.sc.box64_1),
                          const_cast<float *>(ln.sc.box64_2), ln.sc.rem, ln.sc.lv,
-                         reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow, ln.st);
+                         reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow,
+                         after_sort ? reinterpret_cast<float4 *>(base + L.aos1) + s0 * n : nullptr,
+                         after_sort ? reinterpret_cast<float4 *>(base + L.aos2) + s0 * m : nullptr, ln.st);
+        // work that only needs the sorted clouds of this lane's samples (pcc_chamfer_emd: the nearest-neighbour search)
+        if (!rc && after_sort) rc = after_sort(ln.s0, ln.bc, ln.st);
     }
     if (rc) return rc;
 
@@ -2520,7 +2765,8 @@ int launch_pair(const PairArgs &pa, dim3 grid, bool grad, hipStream_t st) {
 }
 
 int match_cost_implicit_impl(int b, int n, int m, const float *xyz1, const float *xyz2, const float *grad_cost,
-                             float *cost, float *grad1, float *grad2, hipStream_t st) {
+                             float *cost, float *grad1, float *grad2, hipStream_t st,
+                             const pcc::ChamferOut *chamfer = nullptr) {
     const WsLayout L(b, n, m);
     static const int q_cols = [] {  // columns per lane (A/B measurements: PCC_AM_PAIRQ=2|4)
         const char *e = std::getenv("PCC_AM_PAIRQ");
@@ -2563,14 +2809,48 @@ int match_cost_implicit_impl(int b, int n, int m, const float *xyz1, const float
         f.out[0] = grad ? grad1 + o * n * 3 : nullptr;
         f.out[1] = grad ? grad2 + o * m * 3 : nullptr;
         f.out[2] = cost + o;
+        if (chamfer) {
+            f.ch_d1 = chamfer->dist1 + o * n; f.ch_d2 = chamfer->dist2 + o * m; f.ch_loss = chamfer->loss + o;
+            f.ch_n = n; f.ch_m = m; f.ch_mean = chamfer->mean;
+        }
         {
             pcc::ProfScope prof("pair_finish_kernel", lst);
             const int blocks = grad ? pcc::ceil_div(std::max(n, m) * 3, 256) : 1;
-            hipLaunchKernelGGL(pair_finish_kernel, dim3(blocks, bc, 3), dim3(256), 0, lst, f);
+            hipLaunchKernelGGL(pair_finish_kernel, dim3(blocks, bc, chamfer ? 4 : 3), dim3(256), 0, lst, f);
         }
         return pcc::check_launch("match_cost(reduce)");
     };
+    // the Chamfer half of a ChamferEMD call: nearest neighbours on the clouds this call has just sorted, both directions
+    // in one launch, then the loss reduction -- on the lane's stream, between the sort and the first pass
+    auto nn_after_sort = [&](int s0, int bc, hipStream_t lst) -> int {
+        const size_t o = (size_t)s0;
+        NNSortedArgs q1{}, q2{};
+        q1.n_q = n; q1.n_c = m; q1.q_n4 = L.n4; q1.c_n4 = L.m4; q1.q_nb = L.nb1; q1.c_nb = L.nb2;
+        q1.groups = L.nb1; q1.batch = bc;
+        q1.q_soa = reinterpret_cast<const float *>(base + L.soa1) + o * 3 * L.n4;
+        q1.c_aos = reinterpret_cast<const float4 *>(base + L.aos2) + o * m;
+        q1.q_box = reinterpret_cast<const float *>(base + L.box1) + o * L.nb1 * 8;
+        q1.c_box = reinterpret_cast<const float *>(base + L.box2) + o * L.nb2 * 8;
+        q1.q_perm = reinterpret_cast<const int *>(base + L.perm1) + o * n;
+        q1.out_d = chamfer->dist1 + o * n; q1.out_i = chamfer->idx1 + o * n;
+        q2.n_q = m; q2.n_c = n; q2.q_n4 = L.m4; q2.c_n4 = L.n4; q2.q_nb = L.nb2; q2.c_nb = L.nb1;
+        q2.groups = L.nb2; q2.batch = bc;
+        q2.q_soa = reinterpret_cast<const float *>(base + L.soa2) + o * 3 * L.m4;
+        q2.c_aos = reinterpret_cast<const float4 *>(base + L.aos1) + o * n;
+        q2.q_box = q1.c_box; q2.c_box = q1.q_box;
+        q2.q_perm = reinterpret_cast<const int *>(base + L.perm2) + o * m;
+        q2.out_d = chamfer->dist2 + o * m; q2.out_i = chamfer->idx2 + o * m;
+        const long long w0 = (long long)bc * q1.groups, w1 = (long long)bc * q2.groups;
+        const long long grid = (w0 + w1 + kNNWaves - 1) / kNNWaves;
+        if (w0 + w1 > 0x7fffffffLL) return pcc::invalid("chamfer_emd: grid too large");
+        {
+            pcc::ProfScope prof("nn_sorted_kernel", lst);
+            hipLaunchKernelGGL(nn_sorted_kernel, dim3((unsigned)grid), dim3(64 * kNNWaves), 0, lst, q1, q2, (int)w0);
+        }
+        return pcc::check_launch("chamfer_emd(nearest neighbours)");  // (the loss reduction rides in the finish launch)
+    };
     bool use_persist = false;
+    if (chamfer) return run_levels(b, n, m, xyz1, xyz2, L, base, st, &use_persist, tail, nn_after_sort);
     return run_levels(b, n, m, xyz1, xyz2, L, base, st, &use_persist, tail);
 }
 
@@ -2581,6 +2861,13 @@ int check_sizes(const char *who, int b, int n, int m) {
 }
 
 }  // namespace
+
+namespace pcc {
+int match_cost_with_chamfer(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
+                            float *grad2, hipStream_t st, const ChamferOut &chamfer) {
+    return match_cost_implicit_impl(b, n, m, xyz1, xyz2, nullptr, cost, grad1, grad2, st, &chamfer);
+}
+}  // namespace pcc
 
 extern "C" {
 

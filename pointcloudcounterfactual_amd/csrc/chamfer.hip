@@ -393,10 +393,13 @@ int pcc_chamfer_loss_grad(int b, int n, const float *xyz1, int m, const float *x
                       static_cast<hipStream_t>(stream));
 }
 
-// Forward of the reference's ChamferEMD reconstruction loss (metrics_and_losses.py:70-79) in one call: Chamfer, then the
-// approximate EMD, on the caller's stream.  (Measured and rejected: the nearest-neighbour search on a side stream "in
-// the shadow" of the EMD's launch chain -- at any starting pass, with or without raised wave priority for the chain --
-// never beat the serial order: the chain's kernels are bound by the vector and LDS pipes, not idle.)
+// Forward of the reference's ChamferEMD reconstruction loss (metrics_and_losses.py:70-79) in one call.  The two losses
+// work on the same pair of clouds, and the approximate EMD starts by Hilbert-sorting both: the nearest-neighbour search
+// runs on those sorted clouds with box culling (nn_sorted_kernel, approxmatch.hip) instead of the exhaustive scan --
+// same indices, same distances, bit for bit (tests/test_gpu_structural.py).
+// (Measured and rejected: the exhaustive search on a side stream "in the shadow" of the EMD's launch chain -- at any
+// starting pass, with or without raised wave priority for the chain -- never beat the serial order: the chain's kernels
+// are bound by the vector and LDS pipes, not idle.)
 int pcc_chamfer_emd(int b, int n, const float *xyz1, int m, const float *xyz2, int mean, float *chamfer_loss,
                     float *dist1, int *idx1, float *dist2, int *idx2, float *emd_cost, float *emd_grad1,
                     float *emd_grad2, pcc_stream_t stream) {
@@ -404,10 +407,13 @@ int pcc_chamfer_emd(int b, int n, const float *xyz1, int m, const float *xyz2, i
     if (b < 0 || n < 0 || m < 0) return pcc::invalid("chamfer_emd: negative size");
     if (b == 0) return PCC_OK;
     if (n == 0 || m == 0) return pcc::invalid("chamfer_emd: one cloud is empty");
+    if ((long long)n * 3 > 0x7fffffffLL || (long long)m * 3 > 0x7fffffffLL) return pcc::invalid("chamfer_emd: bad size");
     if (!xyz1 || !xyz2 || !chamfer_loss || !dist1 || !idx1 || !dist2 || !idx2 || !emd_cost)
         return pcc::invalid("chamfer_emd: null pointer");
-    if (int rc = pcc_chamfer_loss(b, n, xyz1, m, xyz2, mean, chamfer_loss, dist1, idx1, dist2, idx2, stream)) return rc;
-    return pcc_match_cost(b, n, m, xyz1, xyz2, nullptr, emd_cost, emd_grad1, emd_grad2, stream);
+    if ((emd_grad1 == nullptr) != (emd_grad2 == nullptr)) return pcc::invalid("chamfer_emd: emd_grad1 and emd_grad2 go together");
+    const pcc::ChamferOut ch{mean, chamfer_loss, dist1, dist2, idx1, idx2};
+    return pcc::match_cost_with_chamfer(b, n, m, xyz1, xyz2, emd_cost, emd_grad1, emd_grad2,
+                                        static_cast<hipStream_t>(stream), ch);
 }
 
 int pcc_chamfer_emd_grad(int b, int n, const float *xyz1, int m, const float *xyz2, const int *idx1, const int *idx2,

@@ -58,4 +58,14 @@ constexpr unsigned long long kPoolKeepBytes = 1ull << 30;
 hipError_t ws_malloc(void **p, size_t bytes, hipStream_t st);
 hipError_t ws_free(void *p, hipStream_t st);
 
+// The Chamfer half of pcc_chamfer_emd: computed inside the approximate-EMD call, on the clouds that call sorts
+// (approxmatch.hip); the loss reduction rides in that call's finish launch.
+struct ChamferOut {
+    int mean;
+    float *loss, *dist1, *dist2;
+    int *idx1, *idx2;
+};
+int match_cost_with_chamfer(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
+                            float *grad2, hipStream_t st, const ChamferOut &chamfer);
+
 }  // namespace pcc

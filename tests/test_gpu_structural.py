@@ -582,3 +582,48 @@ def test_chamfer_emd_node_equals_separate_losses(cuda, b, n, m, reduction):
     assert torch.equal(lc2, lc)
     # the cost-only kernel takes sqrt(d2) directly, the gradient variant as d2 * rsqrt(d2): 2e-6, as for match_cost
     np.testing.assert_allclose(le2.cpu().numpy(), le.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+
+
+CE_SHAPES = NN_SHAPES + [(2, 40, 1200), (1, 5000, 3000), (1, 17000, 300), (33, 2048, 2048)]
+
+
+@pytest.mark.parametrize('b,n,m', CE_SHAPES)
+@pytest.mark.parametrize('kind', ['recon', 'uniform'])
+def test_chamfer_emd_neighbours_are_the_exhaustive_ones(cuda, b, n, m, kind):
+    """pcc_chamfer_emd finds the nearest neighbours on the clouds the EMD has sorted, visiting only the candidate blocks
+    that can hold one (nn_sorted_kernel): indices and distances carry the bits of the exhaustive pcc_nndistance -- also
+    across candidate chunks (> 2048), for clouds too large for the sort (> 16384: original order, nothing culled) and for
+    batches that run as two lanes."""
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(4000 + n + m, b, n, m, kind)
+    t1, t2 = _dev(a, cuda), _dev(c, cuda)
+    d1, i1, d2, i2 = backend.NNDistance(t1, t2)
+    loss, j1, j2, cost, e1, e2 = backend.ChamferEMD(t1, t2, True, False, return_dist=True)
+    assert torch.equal(j1, i1) and torch.equal(j2, i2)
+    assert torch.equal(e1, d1) and torch.equal(e2, d2)
+    ref_loss = backend.ChamferLoss(t1, t2, True)[0]
+    assert torch.equal(loss, ref_loss)
+    ref_cost, = backend.MatchCostImplicit(t1, t2, False)
+    assert torch.equal(cost, ref_cost)
+
+
+def test_chamfer_emd_neighbour_ties_lowest_original_index(cuda):
+    """Duplicate candidates: the lowest ORIGINAL index must win although the search runs in the sorted order
+    (nndistance.cu:26,36,116)."""
+    from pointcloudcounterfactual_amd import backend
+
+    rng = np.random.default_rng(5)
+    base = rng.random((2, 40, 3), dtype=np.float32)
+    c = np.concatenate([base] * 30, axis=1)  # 1200 candidates, every point repeated 30x
+    a = base[:, ::-1].copy()
+    t1, t2 = _dev(a, cuda), _dev(c, cuda)
+    d1, i1, d2, i2 = backend.NNDistance(t1, t2)
+    _loss, j1, j2, _cost, e1, e2 = backend.ChamferEMD(t1, t2, False, False, return_dist=True)
+    assert torch.equal(j1, i1) and torch.equal(j2, i2) and torch.equal(e1, d1) and torch.equal(e2, d2)
+    assert int(j1.max()) < 40
+    # a cloud against itself: every point is its own nearest neighbour at distance 0
+    s = _dev(rng.random((3, 777, 3), dtype=np.float32), cuda)
+    _loss, j1, j2, _cost, e1, e2 = backend.ChamferEMD(s, s, True, False, return_dist=True)
+    ar = torch.arange(777, device=cuda, dtype=torch.int32).expand(3, -1)
+    assert torch.equal(j1, ar) and torch.equal(j2, ar) and float(e1.abs().max()) == 0.0

@@ -14,7 +14,7 @@ call = rows[lo:hi + 1]
 t0 = call[0]['s']
 def short(n):
     n = n.replace('(anonymous namespace)::', '')
-    m = re.search(r'(am_\w+|pair_\w+)(<[^>(]*>)?', n)
+    m = re.search(r'(am_\w+|pair_\w+|nn_\w+|chamfer_\w+)(<[^>(]*>)?', n)
     return m.group(0) if m else n[:40]
 last_end = {}
 print('start_us  dur_us  gap_us  queue  kernel')
