@@ -64,6 +64,7 @@ def parse() -> argparse.Namespace:
                     help='start the ranks through torch.distributed.run even for --gpus 1 (exercises RCCL at world 1)')
     ap.add_argument('--phase-probe', action='store_true', help=argparse.SUPPRESS)  # child of the no-skip measurement
     ap.add_argument('--no-dist-init', action='store_true', help=argparse.SUPPRESS)  # diagnosis: launcher without RCCL
+    ap.add_argument('--no-noskip', action='store_true', help='skip the child process of the no-skip roofline (profiling runs)')
     ap.add_argument('--kind', choices=['recon', 'uniform'], default='recon', help=argparse.SUPPRESS)
     ap.add_argument('--emd-mode', choices=['implicit', 'fused', 'reference'], default='implicit',
                     help="how match_cost carries out ApproxMatch -> MatchCost / MatchCostGrad (losses.MatchCostFunction.mode): "
@@ -491,7 +492,7 @@ def main() -> int:
         pmc = os.path.join(ROOT, 'profiles', 'pmc_summary.json')
         if os.path.exists(pmc) and ok:
             try:
-                fam = json.load(open(pmc)).get('am_phase_kernel', {})
+                fam = json.load(open(pmc)).get('am_phase+am_fine', {})
                 traffic = fam.get('hbm_bytes_per_launch')
                 insts = fam.get('valu_insts_per_launch')
                 trans = fam.get('trans_insts_per_launch')
@@ -507,7 +508,7 @@ def main() -> int:
             except Exception:
                 traffic = executed = None
         roof = {
-            'kernel': 'am_phase_kernel (approxmatch passes A/B/C, 19 launches per forward)',
+            'kernel': 'am_fine_kernel / am_phase_kernel (approxmatch passes A/B/C: 19 launches per forward, 7 of them am_fine_kernel)',
             'bound': 'mfma',
             'bound_detail': 'f32 VALU + transcendental pipe, priced at the f32 vector rate 157.3 TFLOP/s (= 78.6 T lane '
                             'issue slots/s x 2; numerically the f32 dense MFMA peak); no MFMA is used: the kernel is an '
@@ -536,7 +537,7 @@ def main() -> int:
                                'flop_per_launch': algo_flop_per_launch,
                                'note': 'counts the exactly-zero terms the kernels skip; may exceed 1'}
         try:
-            roof['noskip'] = noskip_roofline(k2)
+            roof['noskip'] = noskip_roofline(k2) if not args.no_noskip else {'skipped': '--no-noskip'}
             if roof['frac'] is None and 'frac' in roof['noskip']:
                 roof['achieved'], roof['frac'] = roof['noskip']['achieved'], roof['noskip']['frac']
         except Exception as e:

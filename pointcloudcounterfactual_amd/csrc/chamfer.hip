@@ -170,8 +170,18 @@ __global__ __launch_bounds__(64 * S) void nn_fwd_kernel(int b, int n, const floa
     for (int e = tid; e < TQ; e += T) {
         const int q = tile * TQ + e;
         if (q < nq) {
-            out_d[q] = run_best[e];
-            out_i[q] = run_idx[e];
+            float rb = run_best[e];
+            int ri = run_idx[e];
+            // non-finite inputs as the reference treats them (nndistance.cu:26-28, `k == 0 || d < best`): candidate 0 is
+            // always taken first, and nothing compares below NaN -- a NaN query point, or a NaN candidate 0, gives
+            // dist = NaN with index 0; a NaN candidate elsewhere never wins.  The scan above ignores NaN (fminf, strict <).
+            const float d0 = sq3(C[0] - Q[q * 3 + 0], C[1] - Q[q * 3 + 1], C[2] - Q[q * 3 + 2]);
+            if (d0 != d0 || !(rb < __builtin_inff())) {
+                rb = d0;
+                ri = 0;
+            }
+            out_d[q] = rb;
+            out_i[q] = ri;
         }
     }
 }

@@ -12,6 +12,11 @@
 
 namespace {
 
+// A neighbour index outside [0, n) (an index array built for another cloud size, a padding slot) must never become an
+// LDS address: it is replaced by the point itself (torch.gather would raise; a kernel cannot).  Memory safety only --
+// the Python layer documents that indices must lie in [0, n).
+__device__ __forceinline__ int nbr(long long v, int n, int self) { return (unsigned long long)v < (unsigned long long)n ? (int)v : self; }
+
 // Forward: a workgroup owns CB channels of one sample, stages those rows of x in LDS (the gathers then hit
 // LDS instead of 64 different cache lines per wave-instruction) and streams the (n,k) index list.
 //   MODE 0: gather            out[b,c,n,j]  = x[b,c,idx]
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
                 tb[cc] = tl[cc] = 0;
             }
             for (int j = 0; j < k; j++) {
-                const int t = (int)ib[(size_t)i * k + j];
+                const int t = nbr(ib[(size_t)i * k + j], n, i);
 #pragma unroll
                 for (int cc = 0; cc < CB; cc++) {
                     if (cc < cb) {
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
                 bj[cc] = 0;
             }
             for (int j = 0; j < k; j++) {
-                const int t = (int)ib[(size_t)i * k + j];
+                const int t = nbr(ib[(size_t)i * k + j], n, i);
 #pragma unroll
                 for (int cc = 0; cc < CB; cc++) {
                     if (cc < cb) {
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
         const int out_c = MODE == 1 ? 2 * c : c;
         float *ob = out + (size_t)smp * out_c * nk;
         for (size_t e = tid; e < nk; e += T) {
-            const int t = (int)ib[e];
             const int i = (int)(e / k);
+            const int t = nbr(ib[e], n, i);
 #pragma unroll
             for (int cc = 0; cc < CB; cc++) {
                 if (cc < cb) {
@@ -155,15 +160,15 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(int c, int n, int k, 
                 const int ch = c0 + cc;
                 if (ch < c) {
                     const int j = argmax[((size_t)smp * c + ch) * n + i];
-                    const int t = (int)ib[(size_t)i * k + j];
+                    const int t = nbr(ib[(size_t)i * k + j], n, i);
                     atomicAdd(&bins[cc * n + t], g[((size_t)smp * c + ch) * n + i]);
                 }
             }
         }
     } else {
         for (size_t e = tid; e < nk; e += T) {
-            const int t = (int)ib[e];
             const int i = (int)(e / k);
+            const int t = nbr(ib[e], n, i);
 #pragma unroll
             for (int cc = 0; cc < CB; cc++) {
                 const int ch = c0 + cc;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(1024) void edge_sort_kernel(int n, int k, const int
     unsigned *out = rev + (size_t)smp * nk;
     for (int i = tid; i < n; i += T) cur[i] = 0;
     __syncthreads();
-    for (size_t e = tid; e < nk; e += T) atomicAdd(&cur[(int)ib[e]], 1);
+    for (size_t e = tid; e < nk; e += T) atomicAdd(&cur[nbr(ib[e], n, (int)(e / k))], 1);
     __syncthreads();
     // exclusive scan of the n counts: every thread owns a contiguous run
     const int per = (n + T - 1) / T;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(1024) void edge_sort_kernel(int n, int k, const int
     }
     __syncthreads();
     for (size_t e = tid; e < nk; e += T) {
-        const int t = (int)ib[e];
+        const int t = nbr(ib[e], n, (int)(e / k));
         const int pos = atomicAdd(&cur[t], 1);
         out[pos] = (unsigned)(e / k) | ((unsigned)t << 16);
     }

@@ -34,7 +34,7 @@ struct SmallLayout {
 
 // Merge S sorted K-lists per lane (LDS layout [s][slot][lane]) and write the first k indices as int64.
 template <int K, int S>
-__device__ __forceinline__ void merge_and_store(const float *md, const int *mi, int lane, int k, int64_t *dst) {
+__device__ __forceinline__ void merge_and_store(const float *md, const int *mi, int lane, int k, int64_t *dst, int n) {
     int p[S];
     float h[S];
 #pragma unroll
@@ -54,7 +54,8 @@ __device__ __forceinline__ void merge_and_store(const float *md, const int *mi, 
         int pos = 0;
 #pragma unroll
         for (int s = 0; s < S; s++) pos = (best == s) ? p[s] : pos;
-        dst[o] = (int64_t)mi[(best * K + pos) * 64 + lane];
+        // (a list can run out only when distances are NaN: never emit an index outside the cloud)
+        dst[o] = (int64_t)min(mi[(best * K + pos) * 64 + lane], n - 1);
         const int np = pos + 1;
         const float nh = np < K ? md[(best * K + np) * 64 + lane] : __builtin_inff();
 #pragma unroll
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(64 * S) void knn_small_kernel(int c, int n, int k, 
         mrg_i[(w * K + s) * 64 + lane] = tk.top.i[s];
     }
     __syncthreads();
-    if (w == 0 && q_ok) merge_and_store<K, S>(mrg_d, mrg_i, lane, k, indices + ((size_t)smp * n + q) * k);
+    if (w == 0 && q_ok) merge_and_store<K, S>(mrg_d, mrg_i, lane, k, indices + ((size_t)smp * n + q) * k, n);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256, CP >= 128 ? 2 : 1) void knn_mfma_kernel(int c,
             const int ia = p0 < K ? i0[p0 * 32] : 0x7fffffff;
             const int ib = p1 < K ? i1[p1 * 32] : 0x7fffffff;
             const bool take0 = (a < bb) || (a == bb && ia < ib);
-            dst[o] = (int64_t)(take0 ? ia : ib);
+            dst[o] = (int64_t)min(take0 ? ia : ib, n - 1);
             p0 += take0 ? 1 : 0;
             p1 += take0 ? 0 : 1;
         }

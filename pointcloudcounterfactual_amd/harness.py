@@ -188,6 +188,35 @@ class DGCNNEncoder(nn.Module):
         return ops.global_max_pool(self.features(cloud))
 
 
+class LDGCNNEncoder(nn.Module):
+    """The reference's lighter encoder (``src/module/encoders.py:62-91``): ONE kNN graph on the input cloud, one EdgeConv
+    layer, then ``graph_max_pooling`` over that fixed graph before every 1x1 convolution (``conv_dims`` from
+    ``lgcnn.yaml``-style configurations), concatenation, final convolution, global max.  kNN, the fused EdgeConv front-end,
+    the max over neighbours and the global max are this package's HIP kernels."""
+
+    def __init__(self, k: int = 25, w_dim: int = 1024, conv_dims: tuple[int, ...] = (64, 64, 128, 256),
+                 fused: bool = True) -> None:
+        super().__init__()
+        self.k, self.fused = k, fused
+        self.edge_conv = FusedEdgeConv(3, conv_dims[0]) if fused else EdgeConv(6, conv_dims[0])
+        self.points_convolutions = nn.ModuleList(
+            [PointsConv(a, b, nn.LeakyReLU(0.2)) for a, b in itertools.pairwise(conv_dims)])
+        self.final_conv = PointsConv(sum(conv_dims), w_dim, bn=False)
+
+    def forward(self, cloud: torch.Tensor) -> torch.Tensor:
+        x = cloud.transpose(2, 1).contiguous()
+        idx = ops.knn(x, self.k)
+        if self.fused:
+            x = self.edge_conv(x, idx)
+        else:
+            x = self.edge_conv(ops.get_graph_features(x, idx, self.k)[1]).max(dim=3)[0]
+        xs = [x]
+        for conv in self.points_convolutions:
+            x = conv(ops.graph_max_pooling(x, idx, self.k))
+            xs.append(x)
+        return ops.global_max_pool(self.final_conv(torch.cat(xs, dim=1).contiguous()))
+
+
 class DGCNNClassifier(nn.Module):
     """classifier.py:18-66 with dgcnn.yaml: k=20, conv (64,64,128,256), feature 512, mlp (512,256), 40 classes."""
 

@@ -195,3 +195,33 @@ def test_counterfactual_step_at_config5_workload(cuda):
         p0 = fused.w_autoencoder.interpolated_probs(logits, 3, 0.0)
     np.testing.assert_allclose(p0.cpu().numpy(), torch.softmax(logits / 5.0, 1).cpu().numpy(), rtol=1e-6)
     print(f'config-5 step: identical codes {same:.4f}')
+
+
+def test_ldgcnn_encoder_variant(cuda):
+    """The reference's LDGCNN encoder (encoders.py:62-91: one graph, graph_max_pooling before every 1x1 convolution): fused
+    EdgeConv front-end == reference composition on the same weights (the graph is built on the input cloud, so both
+    see the same one), forward and backward, and the HIP graph_max_pooling == the dense gather + max."""
+    from pointcloudcounterfactual_amd import harness
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    _, ref = pair(21, 4, 1024, 1024)
+    ref_t = torch.from_numpy(ref).to(cuda)
+    torch.manual_seed(3)
+    unfused = harness.LDGCNNEncoder(k=20, w_dim=256, fused=False).to(cuda).train()
+    fused = harness.LDGCNNEncoder(k=20, w_dim=256, fused=True).to(cuda).train()
+    _clone_into(fused, unfused)
+    w = torch.randn(4, 256, device=cuda)
+    outs = []
+    for model in (unfused, fused):
+        out = model(ref_t)
+        assert out.shape == (4, 256)
+        (out * w).sum().backward()
+        outs.append((out.detach(), [p.grad.detach().clone() for p in model.parameters()]))
+    torch.testing.assert_close(outs[1][0], outs[0][0], rtol=2e-3, atol=2e-3)
+    for g1, g0 in zip(outs[1][1], outs[0][1]):
+        scale = float(g0.abs().max()) + 1e-6
+        torch.testing.assert_close(g1, g0, rtol=2e-2, atol=5e-3 * scale)
+    x = torch.randn(2, 16, 300, device=cuda)
+    idx = ops.knn(x, 8)
+    dense = torch.gather(x, 2, idx.reshape(2, 1, -1).expand(-1, 16, -1)).view(2, 16, 300, 8).max(-1)[0]
+    assert torch.equal(ops.graph_max_pooling(x, idx, 8), dense)

@@ -627,3 +627,23 @@ def test_chamfer_emd_neighbour_ties_lowest_original_index(cuda):
     _loss, j1, j2, _cost, e1, e2 = backend.ChamferEMD(s, s, True, False, return_dist=True)
     ar = torch.arange(777, device=cuda, dtype=torch.int32).expand(3, -1)
     assert torch.equal(j1, ar) and torch.equal(j2, ar) and float(e1.abs().max()) == 0.0
+
+
+def test_nndistance_non_finite_inputs_follow_the_reference(cuda, oracle_mod):
+    """nndistance.cu:26-28 takes candidate 0 unconditionally and then only strict improvements: a NaN query point gives
+    dist = NaN / index 0, a NaN candidate 0 poisons every query, a NaN candidate elsewhere never wins.  The oracle is the
+    line-by-line restatement of that loop; the HIP kernel must show the same NaN pattern and the same finite results."""
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(77, 2, 300, 257)
+    a[0, 5] = np.nan            # a NaN query in sample 0
+    c[0, 9, 1] = np.nan         # a NaN candidate (not the first) in sample 0
+    c[1, 0, 2] = np.nan         # NaN candidate 0 in sample 1
+    d1, i1, d2, i2 = backend.NNDistance(_dev(a, cuda), _dev(c, cuda))
+    od1, oi1, od2, oi2 = oracle_mod.nndistance(a, c)
+    for got, exp in ((d1, od1), (d2, od2)):
+        g = got.cpu().numpy()
+        assert np.array_equal(np.isnan(g), np.isnan(exp))
+        assert np.array_equal(g[~np.isnan(exp)], exp[~np.isnan(exp)])
+    assert np.array_equal(i1.cpu().numpy(), oi1) and np.array_equal(i2.cpu().numpy(), oi2)
+    assert np.isnan(od1[0, 5]) and np.isnan(od1[1]).all() and not np.isnan(od1[0, :5]).any()

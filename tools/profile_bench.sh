@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-extras ${BENCH_EXTRA:-}"
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-noskip ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $R/bench.py $ARGS > $OUT/${TAG}_stats.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 $R/bench.py $ARGS > $OUT/${TAG}_pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $R/bench.py $ARGS > $OUT/${TAG}_pmc_write.log 2>&1 || exit 1
