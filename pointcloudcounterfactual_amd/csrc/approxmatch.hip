@@ -82,11 +82,9 @@ constexpr float kZeroExp = 151.f; // exp2(x) == 0 exactly for x <= -150 (below t
 
 struct PhaseArgs {
     int n_own, n_cand, tiles, batch;   // tiles = ceil(n_own / (64 R))
-    int xcd;                           // XCD-aware block mapping (PCC_AM_NOXCD=1 turns it off)
     int own_n4, cand_n4, own_nb, cand_nb;
     const float *own_soa, *cand_soa;   // [b][3][n4] Hilbert-sorted coordinates
-    const float *own_box, *cand_box;   // own: [b][ceil(n/64)][8] per 64 sorted points; cand: [b][nb][8] per 16 (min xyz,0,max xyz,0)
-    int own_nb64;
+    const float *cand_box;             // [b][nb][8] per 16 sorted candidates (min xyz, 0, max xyz, 0)
     const float *own_box16;            // [b][own_nb][8] per 16 sorted owners (am_fine_kernel)
     const float *w0, *w1;              // per-candidate weights in sorted order (w0 may be null => w0c)
     long long w0_stride, w1_stride;    // per-sample strides in floats
@@ -113,30 +111,28 @@ struct PhaseArgs {
     int *stamp;                        // optional [3][8] s_memrealtime stamps of the first / middle / last workgroup (PCC_AM_DEBUG=2)
 };
 
-// Work-skipping variants of a phase launch.  All of them only drop terms that are EXACTLY zero:
-//   V_CULL  (fine levels): a (64-owner group, 16-candidate block) pair is skipped when the box distance makes
-//           every exp2(c*d2) underflow to 0;
-//   V_CCAND (pass C/A from level 2 on): candidates whose weights are all 0 are compacted away while staging --
-//           a query point whose capacity is used up has remainR == ratioR == 0 from then on (approxmatch.cu:108-109),
-//           typically 54 % of them by level 3 and 95 % by level 8;
-//   V_COWN  (pass B from level 3 on): the same exhausted points as OWNERS: their outputs are ratioR = 0,
-//           remainR = 0 whatever the sum is, so only the live owners are gathered into tiles (the level arrays
-//           are zero-filled beforehand) and workgroups beyond the live count exit.
-//   V_CLIST (pass C/A from level 3 on): the same candidates as V_CCAND, but the compaction is already done: the live
-//           owners of the preceding V_COWN pass B ARE the candidates with a non-zero weight (ratioR_i = consumption *
-//           remainR != 0 exactly for them), so that pass writes their coordinates and new weights as a dense list
-//           and this one stages it with straight float4 copies (no scan, no scattered LDS stores).
-enum Var { V_PLAIN = 0, V_CULL = 1, V_CCAND = 2, V_COWN = 3, V_CLIST = 4 };
+// Work-skipping variants of a pass launch.  All of them only drop terms that are EXACTLY zero:
+//   V_CULL  (levels 0-2, am_fine_kernel): a (16-owner group, 16-candidate block) pair is skipped when the box distance
+//           makes every exp2(c*d2) underflow to 0;
+//   V_COWN  (pass B from level 3 on): a query point whose capacity is used up has remainR == ratioR == 0 from then on
+//           (approxmatch.cu:108-109; 54 % of them by level 3 and 95 % by level 8 on the bench clouds): its outputs are
+//           ratioR = 0, remainR = 0 whatever the sum is, so only the live owners are gathered into tiles (the level
+//           arrays are zero-filled beforehand) and workgroups beyond the live count leave at once;
+//   V_CLIST (pass C/A from level 3 on): the same exhausted points as CANDIDATES: the live owners of the preceding
+//           V_COWN pass B ARE the candidates with a non-zero weight (ratioR_i = consumption * remainR != 0 exactly for
+//           them), so that pass writes their coordinates and new weights as a dense list and this one stages it with
+//           straight float4 copies (no scan, no scattered LDS stores).
+enum Var { V_PLAIN = 0, V_CULL = 1, V_COWN = 3, V_CLIST = 4 };
 
 // Everything a pass needs is derived from this small description of one approxmatch call: the same function
-// builds the arguments of pass p for the per-launch schedule (host) and inside the persistent kernel (device).
+// builds the arguments of pass p.
 //   p = 0: pass A of level 0;  p = 1 + 2i: pass B of level i;  p = 2 + 2i: pass C of level i fused with pass A of
 //   level i+1 (plain pass C for the last level).
 struct Sched {
-    int n, m, n4, m4, nb1, nb2, nb64_1, nb64_2;
-    const float *soa1, *soa2, *box1, *box2, *box64_1, *box64_2;
+    int n, m, n4, m4, nb1, nb2;
+    const float *soa1, *soa2, *box1, *box2;
     float *rem, *lv;               // sorted space: remain row = remainL(n4) | remainR ping(m4) | pong(m4); level rows
-    float multiL, multiR, cut_scale;
+    float multiL, multiR;
     float *clist;                  // dense candidate list handed from pass B to pass C/A (null: pass C/A compacts itself)
     int *clist_cnt;
     int *live_cnt;                 // [b][kLiveRow] live set2 points entering pass B of level i (zeroed by the sort; i >= 1)
@@ -157,11 +153,11 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
     const bool set1_owns = (p == 0) || (p % 2 == 0);
     if (set1_owns) {  // owners = set1, candidates = set2
         a.n_own = sc.n; a.n_cand = sc.m; a.own_n4 = sc.n4; a.cand_n4 = sc.m4; a.own_nb = sc.nb1; a.cand_nb = sc.nb2;
-        a.own_soa = sc.soa1; a.cand_soa = sc.soa2; a.own_box = sc.box64_1; a.own_nb64 = sc.nb64_1; a.cand_box = sc.box2;
+        a.own_soa = sc.soa1; a.cand_soa = sc.soa2; a.cand_box = sc.box2;
         a.own_box16 = sc.box1;
     } else {          // owners = set2, candidates = set1
         a.n_own = sc.m; a.n_cand = sc.n; a.own_n4 = sc.m4; a.cand_n4 = sc.n4; a.own_nb = sc.nb2; a.cand_nb = sc.nb1;
-        a.own_soa = sc.soa2; a.cand_soa = sc.soa1; a.own_box = sc.box64_2; a.own_nb64 = sc.nb64_2; a.cand_box = sc.box1;
+        a.own_soa = sc.soa2; a.cand_soa = sc.soa1; a.cand_box = sc.box1;
         a.own_box16 = sc.box2;
     }
     int mode, var;
@@ -170,7 +166,7 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
         var = sc.skip ? V_CULL : V_PLAIN;
         a.level = 0;
         a.w0 = nullptr; a.w0c = sc.multiR; a.c0 = sc.lc.c[0]; a.first = 1;
-        a.cut2 = sc.cut_scale * kZeroExp / -sc.lc.c[0];
+        a.cut2 = kZeroExp / -sc.lc.c[0];
         a.ratio_out = sc.lv; a.ratio_stride = kLevels * nm4;
         a.dbg = sc.dbg_counts ? sc.dbg : nullptr;
     } else {
@@ -184,7 +180,7 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
             // box culling while the zero radius is small against the cloud (levels 0-2), live-owner compaction after
             var = !sc.skip ? V_PLAIN : i <= 2 ? V_CULL : V_COWN;
             a.w0 = ratioL; a.w0_stride = kLevels * nm4;
-            a.cut2 = sc.cut_scale * kZeroExp / -sc.lc.c[i];
+            a.cut2 = kZeroExp / -sc.lc.c[i];
             a.remain = sc.rem + sc.n4 + (i & 1) * sc.m4;
             a.remain_out = sc.rem + sc.n4 + ((i + 1) & 1) * sc.m4;
             a.remain_stride = rs;
@@ -198,14 +194,16 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
         } else {           // pass C of level i (+ pass A of level i+1)
             mode = i + 1 < kLevels ? PH_CA : PH_C;
             // (the cull radius is the one of level i+1); from level 3 on pass B has left the dense candidate list
-            var = !sc.skip ? V_PLAIN : i <= 1 ? V_CULL : (i == 2 || !sc.clist) ? V_CCAND : V_CLIST;
+            // (level 2: the (16 x 16) boxes still drop half of the pairs at level 3's radius, more than compacting away
+            // the exhausted candidates did)
+            var = !sc.skip ? V_PLAIN : i <= 2 ? V_CULL : V_CLIST;
             if (var == V_CLIST) { a.clist = sc.clist; a.clist_cnt = sc.clist_cnt; a.cl_n4 = sc.m4; }
             a.w0 = ratioR; a.w0_stride = kLevels * nm4;
             a.w1 = sc.rem + sc.n4 + ((i + 1) & 1) * sc.m4; a.w1_stride = rs;
             a.remain = sc.rem; a.remain_stride = rs;
             a.ratio_in = ratioL; a.ratio_stride = kLevels * nm4;
             const int lc_i = i + 1 < kLevels ? i + 1 : i;
-            a.cut2 = sc.cut_scale * kZeroExp / -sc.lc.c[lc_i];  // the coarser of the two levels decides what is 0
+            a.cut2 = kZeroExp / -sc.lc.c[lc_i];  // the coarser of the two levels decides what is 0
             if (i + 1 < kLevels) {
                 a.c1 = sc.lc.c[i + 1];
                 a.ratio_out = sc.lv + (size_t)(i + 1) * nm4;
@@ -219,79 +217,36 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
     return a;
 }
 
-// order-preserving compaction step shared by V_CCAND / V_COWN: position of this thread's element among the
-// flagged elements of the whole workgroup round (wave ballots + an S-entry LDS scan)
-template <int S>
-__device__ __forceinline__ int compact_pos(bool flag, int w, int lane, int *wave_cnt, int &round_total) {
-    const unsigned long long bal = __ballot(flag);
-    const int lane_off = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_cnt[w] = __popcll(bal);
-    __syncthreads();
-    int before = 0, total = 0;
-#pragma unroll
-    for (int i = 0; i < S; i++) {
-        const int c = wave_cnt[i];
-        before += i < w ? c : 0;
-        total += c;
-    }
-    __syncthreads();  // wave_cnt may be rewritten by the next round
-    round_total = total;
-    return before + lane_off;
-}
-
-// Loads / stores of the vectors that workgroups of one sample hand to each other between passes (ratioL, ratioR,
-// remainR).  In the multi-launch schedule the kernel boundary orders them; inside the persistent kernel they are
-// agent-scope (sc1, write-through / L1-bypassing) accesses behind the sample barrier (cdna guide, Guideline 16).
-template <bool PERSIST>
-__device__ __forceinline__ float xld(const float *p) {
-    if (PERSIST) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool PERSIST>
-__device__ __forceinline__ float4 xld4(const float *p) {  // p is 16-byte aligned
-    if (PERSIST) return make_float4(xld<true>(p), xld<true>(p + 1), xld<true>(p + 2), xld<true>(p + 3));
-    return *reinterpret_cast<const float4 *>(p);
-}
-template <bool PERSIST>
-__device__ __forceinline__ void xst(float *p, float v) {
-    if (PERSIST) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
-// LDS footprint of one phase (floats / ints), shared by the per-launch kernels and the persistent kernel
+// LDS footprint of one phase (floats / ints)
 template <int NW, int R, int S, int CH>
 struct PhaseLds {
     static constexpr int kC = (3 + NW) * CH;          // x | y | z | w0 | (w1)
-    static constexpr int kBB = (CH / kBox) * 8;       // candidate block boxes
     static constexpr int kRed = NW * S * 64 * R;      // partial sums [NW][S][TQ]
     static constexpr int kOwn = 64 * R;               // live-owner tile (ints)
     static constexpr int kWave = S;                   // (ints)
-    static constexpr int kItems = CH / kBox;          // surviving candidate blocks of V_CULL (ints)
-    static constexpr int floats = kC + kBB + kRed + kOwn + kWave + 4 + kItems;
+    static constexpr int floats = kC + kRed + kOwn + kWave + 4;
 };
 
 // G > 1 (owner-compacted passes of the late levels only): a wave holds 64 / G owners, each on G lanes that split the
 // 16-candidate blocks among them (G-fold shorter pair loop for the few live owners left; the partial sums of the G
 // lanes meet through log2(G) shuffles, in a fixed order).
-template <int MODE, int R, int S, int CH, int VAR, bool PERSIST, int G = 1>
+template <int MODE, int R, int S, int CH, int VAR, int G = 1>
 __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int tile, float *smem) {
     constexpr int T = 64 * S;
     constexpr int TQ = 64 * R / G;     // owners per workgroup
     constexpr int PQ = 64 * R;         // pitch of the partial-sum rows in LDS
-    static_assert(G == 1 || (VAR == V_COWN && R == 1 && !PERSIST), "lane-split owners: owner-compacted launches only");
+    static_assert(G == 1 || (VAR == V_COWN && R == 1), "lane-split owners: owner-compacted launches only");
     constexpr int NW = (MODE == PH_CA) ? 2 : 1;
     constexpr bool W0_CONST = (MODE == PH_A);
-    constexpr bool CULL = VAR == V_CULL, CCAND = VAR == V_CCAND, COWN = VAR == V_COWN, CLIST = VAR == V_CLIST;
-    static_assert(!((CCAND || CLIST) && W0_CONST), "pass A of the first level has constant weights");
-    static_assert(!(CLIST && PERSIST), "the dense candidate list is a hand-off between launches");
+    constexpr bool COWN = VAR == V_COWN, CLIST = VAR == V_CLIST;
+    static_assert(VAR == V_PLAIN || COWN || CLIST, "the box-culled passes run on am_fine_kernel");
+    static_assert(!(CLIST && W0_CONST), "pass A of the first level has constant weights");
     static_assert(TQ <= T, "one epilogue owner per thread");
     using L = PhaseLds<2, R, S, CH>;  // offsets do not depend on NW so that every phase sees the same carve
     float *lds_c = smem;                               // x | y | z | w0 | (w1)
-    float *lds_bb = smem + L::kC;
-    float *red = lds_bb + L::kBB;                      // [NW][S][TQ]
+    float *red = smem + L::kC;                         // [NW][S][TQ]
     int *own_idx = reinterpret_cast<int *>(red + L::kRed);
     int *wave_cnt = own_idx + L::kOwn;
-    int *items = wave_cnt + L::kWave + 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -306,7 +261,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     // normal runs (one predicated-off scalar branch per stamp)
     unsigned long long tst0 = 0;
     int *stamp = nullptr;
-    if (!PERSIST && a.stamp && threadIdx.x == 0) {
+    if (a.stamp && threadIdx.x == 0) {
         const unsigned bx = blockIdx.x, gx = gridDim.x;
         const int which = bx == 0 ? 0 : bx == gx / 2 ? 1 : bx == gx - 1 ? 2 : -1;
         if (which >= 0) {
@@ -317,7 +272,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     }
 #define PCC_ST(k) do { if (stamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[(k)] = (int)(__builtin_amdgcn_s_memrealtime() - tst0); } } while (0)
     // ---- which owners does this workgroup hold? ----
-    if (!COWN && tile * TQ >= a.n_own) return;         // (persistent kernel: the two clouds may need different tile counts)
+    if (!COWN && tile * TQ >= a.n_own) return;
     int n_valid = min(TQ, a.n_own - tile * TQ);  // owners of this tile (sorted positions tile*TQ ...)
     if (COWN) {
         // live owners (remain != 0) of the sample, in order; this workgroup takes the tile-th group of TQ.
@@ -336,13 +291,13 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
 #pragma unroll
             for (int v = 0; v < V4; v++) {
                 rv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (beg + 4 * v < end) rv[v] = xld4<PERSIST>(rem + beg + 4 * v);
+                if (beg + 4 * v < end) rv[v] = *reinterpret_cast<const float4 *>(rem + beg + 4 * v);
             }
 #pragma unroll
             for (int v = 0; v < V4; v++)
                 mine += (rv[v].x != 0.f) + (rv[v].y != 0.f) + (rv[v].z != 0.f) + (rv[v].w != 0.f);
         } else {
-            for (int i = beg; i < end; i++) mine += xld<PERSIST>(rem + i) != 0.f ? 1 : 0;
+            for (int i = beg; i < end; i++) mine += rem[i] != 0.f ? 1 : 0;
         }
         // exclusive scan of `mine` over the workgroup: wave scan + S-entry LDS scan
         int incl = mine;
@@ -368,7 +323,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             } else if (tile == 0 && i < a.n_own) {
                 // an exhausted owner keeps remainR = 0 (and ratioR = 0 from the zero-filled level array); the
                 // first workgroup of the sample carries the zero over into the output buffer
-                xst<PERSIST>(&a.remain_out[(size_t)smp * a.remain_stride + i], 0.f);
+                a.remain_out[(size_t)smp * a.remain_stride + i] = 0.f;
             }
         };
         if (fast) {
@@ -383,7 +338,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
                 }
             }
         } else {
-            for (int i = beg; i < end; i++) place(i, xld<PERSIST>(rem + i) != 0.f);
+            for (int i = beg; i < end; i++) place(i, rem[i] != 0.f);
         }
         if (a.dbg && tile == 0 && tid == 0) {
             atomicAdd(&a.dbg[0], a.n_own);
@@ -410,25 +365,11 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         s0[r] = 0.f;
         s1[r] = 0.f;
     }
-    // bounding boxes of the R groups of 64 owners this workgroup holds (wave-uniform), precomputed by the sort
-    float olx[R], oly[R], olz[R], ohx[R], ohy[R], ohz[R];
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        olx[r] = oly[r] = olz[r] = __builtin_inff();
-        ohx[r] = ohy[r] = ohz[r] = -__builtin_inff();
-        if (CULL) {
-            const int g64 = min((tile * TQ + r * 64) / 64, a.own_nb64 - 1);
-            const float4 *ob = reinterpret_cast<const float4 *>(a.own_box + ((size_t)smp * a.own_nb64 + g64) * 8);
-            const float4 lo = ob[0], hi = ob[1];
-            olx[r] = lo.x; oly[r] = lo.y; olz[r] = lo.z;
-            ohx[r] = hi.x; ohy[r] = hi.y; ohz[r] = hi.z;
-        }
-    }
     // operands of the epilogue do not depend on the pair loop: fetch them now, behind the staging traffic
     float pre_rem = 0.f, pre_ratio = 0.f;
     if (own_e >= 0) {
-        if (MODE != PH_A && !a.first) pre_rem = xld<PERSIST>(&a.remain[(size_t)smp * a.remain_stride + own_e]);
-        if (MODE == PH_CA || MODE == PH_C) pre_ratio = xld<PERSIST>(&a.ratio_in[(size_t)smp * a.ratio_stride + own_e]);
+        if (MODE != PH_A && !a.first) pre_rem = a.remain[(size_t)smp * a.remain_stride + own_e];
+        if (MODE == PH_CA || MODE == PH_C) pre_ratio = a.ratio_in[(size_t)smp * a.ratio_stride + own_e];
     }
     PCC_ST(1);
     const float4 *X4 = reinterpret_cast<const float4 *>(lds_c);
@@ -436,8 +377,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     const float4 *Z4 = Y4 + CH / 4;
     const float4 *A4 = Z4 + CH / 4;
     const float4 *B4 = A4 + CH / 4;
-    const float4 *BB4 = reinterpret_cast<const float4 *>(lds_bb);
-    const float c0 = a.c0, c1 = a.c1, cut2 = a.cut2;
+    const float c0 = a.c0, c1 = a.c1;
 
     const int n_cand = CLIST ? __builtin_amdgcn_readfirstlane(a.clist_cnt[smp]) : a.n_cand;
     if (CLIST) {  // dense list of this sample: x | y | z | ratioR (w0) | remainR (w1), rows of cl_n4 floats
@@ -450,60 +390,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         const int cnt = min(CH, n_cand - q0);
         int ngroups = (cnt + 3) / 4;
         if (q0) __syncthreads();
-        if (CCAND) {
-            // stage only the candidates that can contribute (some weight != 0), order preserved.  Every thread
-            // owns a contiguous run of PER candidates (all their loads in flight together), one block scan places them.
-            constexpr int PER = (CH + T - 1) / T;
-            const int beg = tid * PER;
-            float cv0[PER], cv1[PER], cvx[PER], cvy[PER], cvz[PER];
-            int mine = 0;
-#pragma unroll
-            for (int j = 0; j < PER; j++) {
-                const int i = beg + j;
-                const bool in = i < cnt;
-                cv0[j] = in ? xld<PERSIST>(W0 + q0 + i) : 0.f;
-                cv1[j] = (NW == 2 && in) ? xld<PERSIST>(W1 + q0 + i) : 0.f;
-                cvx[j] = in ? C[q0 + i] : 0.f;
-                cvy[j] = in ? C[(size_t)a.cand_n4 + q0 + i] : 0.f;
-                cvz[j] = in ? C[(size_t)2 * a.cand_n4 + q0 + i] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < PER; j++) mine += (cv0[j] != 0.f || cv1[j] != 0.f) ? 1 : 0;
-            PCC_ST(2);
-            int incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off, 64);
-                incl += lane >= off ? v : 0;
-            }
-            if (lane == 63) wave_cnt[w] = incl;
-            __syncthreads();
-            int before = 0, running = 0;
-#pragma unroll
-            for (int i = 0; i < S; i++) {
-                const int c = wave_cnt[i];
-                before += i < w ? c : 0;
-                running += c;
-            }
-            int pos = before + incl - mine;
-#pragma unroll
-            for (int j = 0; j < PER; j++) {
-                if (cv0[j] != 0.f || cv1[j] != 0.f) {
-                    lds_c[pos] = cvx[j];
-                    lds_c[CH + pos] = cvy[j];
-                    lds_c[2 * CH + pos] = cvz[j];
-                    lds_c[3 * CH + pos] = cv0[j];
-                    if (NW == 2) lds_c[4 * CH + pos] = cv1[j];
-                    pos++;
-                }
-            }
-            ngroups = (running + 3) / 4;
-            if (tid < ngroups * 4 - running) {  // zero the tail of the last group
-                const int pos = running + tid;
-                lds_c[pos] = lds_c[CH + pos] = lds_c[2 * CH + pos] = lds_c[3 * CH + pos] = 0.f;
-                if (NW == 2) lds_c[4 * CH + pos] = 0.f;
-            }
-        } else {
+        {
             // sorted SoA rows and the weight rows are padded to a multiple of 4 (zeros): straight float4 copies,
             // all loads of a thread issued before the first LDS store
             float4 *dst4 = reinterpret_cast<float4 *>(lds_c);
@@ -515,8 +402,8 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             for (int i = tid; i < ngroups; i += T) {
                 const float4 vx = sx[i], vy = sy[i], vz = sz[i];
                 float4 v0 = make_float4(a.w0c, a.w0c, a.w0c, a.w0c), v1 = v0;
-                if (!W0_CONST) v0 = xld4<PERSIST>(sw0 + 4 * i);
-                if (NW == 2) v1 = xld4<PERSIST>(sw1 + 4 * i);
+                if (!W0_CONST) v0 = *reinterpret_cast<const float4 *>(sw0 + 4 * i);
+                if (NW == 2) v1 = *reinterpret_cast<const float4 *>(sw1 + 4 * i);
                 if ((W0_CONST || CLIST) && i * 4 + 3 >= cnt) {  // padded candidates must weigh 0 (the list's tail is stale)
                     v0.x = i * 4 + 0 < cnt ? v0.x : 0.f;
                     v0.y = i * 4 + 1 < cnt ? v0.y : 0.f;
@@ -537,58 +424,10 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             }
         }
         const int nblk = (ngroups + 3) / 4;  // blocks of 16 candidates (4 groups)
-        if (CULL) {
-            const float *cb = a.cand_box + ((size_t)smp * a.cand_nb + q0 / kBox) * 8;
-            for (int i = tid; i < nblk * 8; i += T) lds_bb[i] = cb[i];
-        }
         __syncthreads();
         PCC_ST(3);
-        // V_CULL: the (owner group, candidate block) box tests are done once, one block per thread, and the blocks some
-        // owner group needs are compacted (in order) into a work list: nothing is tested inside the pair loop and
-        // the S waves take the SURVIVING blocks round-robin, i.e. evenly (dealing all blocks round-robin left the
-        // workgroup waiting 20-30 % of the loop for the wave that happened to keep the most).  Round-robin rather
-        // than contiguous slices: a contiguous slice of the Hilbert order is one compact region.
-        int nitems = nblk;
-        if (CULL) {
-            int base_cnt = 0;
-            for (int b0 = 0; b0 < nblk; b0 += T) {
-                const int blk = b0 + tid;
-                int mask = 0;
-                if (blk < nblk) {
-                    const float4 lo = BB4[2 * blk], hi = BB4[2 * blk + 1];
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const float dx = fmaxf(fmaxf(olx[r] - hi.x, lo.x - ohx[r]), 0.f);
-                        const float dy = fmaxf(fmaxf(oly[r] - hi.y, lo.y - ohy[r]), 0.f);
-                        const float dz = fmaxf(fmaxf(olz[r] - hi.z, lo.z - ohz[r]), 0.f);
-                        // every pair of (owner group r, candidate block) has |d|^2 >= lb: all exponentials are exactly 0
-                        const bool keep = !(dx * dx + dy * dy + dz * dz > cut2);
-                        mask |= keep ? (1 << r) : 0;
-                    }
-                    if (a.dbg) {
-                        atomicAdd(&a.dbg[0], R);
-                        atomicAdd(&a.dbg[1], R - __popc(mask));
-                    }
-                }
-                int round_total;
-                const int pos = compact_pos<S>(mask != 0, w, lane, wave_cnt, round_total);
-                if (mask) items[base_cnt + pos] = blk | (mask << 16);
-                base_cnt += round_total;
-            }
-            __syncthreads();
-            nitems = base_cnt;
-        }
-        for (int it = w; it < nitems; it += S) {
-            int blk = it;
-            int live[R];  // wave-uniform: does owner group r need this candidate block at all?
-#pragma unroll
-            for (int r = 0; r < R; r++) live[r] = 1;
-            if (CULL) {
-                const int item = __builtin_amdgcn_readfirstlane(items[it]);
-                blk = item & 0xffff;
-#pragma unroll
-                for (int r = 0; r < R; r++) live[r] = (item >> (16 + r)) & 1;
-            }
+        // the S waves take the 16-candidate blocks round-robin
+        for (int blk = w; blk < nblk; blk += S) {
             const int g_end = min(blk * 4 + 4, ngroups);
             for (int g = blk * 4 + sub; g < g_end; g += G) {
                 const float4 x = X4[g], y = Y4[g], z = Z4[g], wa = A4[g];
@@ -596,7 +435,6 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
                 if (NW == 2) wb = B4[g];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    if (CULL && !live[r]) continue;
                     // (x2-x1)^2+(y2-y1)^2+(z2-z1)^2 with the oracle's rounding order (approxmatch.cu:54)
                     const float d0 = sq3(x.x - ox[r], y.x - oy[r], z.x - oz[r]);
                     const float d1 = sq3(x.y - ox[r], y.y - oy[r], z.y - oz[r]);
@@ -660,20 +498,20 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         }
         if (MODE == PH_A) {
             // ratioL[k] = remainL[k] / (1e-9 + sum)            approxmatch.cu:37,61 (remainL == multiL)
-            xst<PERSIST>(&a.ratio_out[(size_t)smp * a.ratio_stride + o], a.multiL / (1e-9f + t0));
+            a.ratio_out[(size_t)smp * a.ratio_stride + o] = a.multiL / (1e-9f + t0);
         } else if (MODE == PH_B) {
             // approxmatch.cu:106-109
             const float rR = a.first ? a.multiR : pre_rem;
             const float sumr = t0 * rR;
             const float consumption = __builtin_fminf(rR / (sumr + 1e-9f), 1.0f);
             const float ratio_new = consumption * rR, remain_new = __builtin_fmaxf(0.0f, rR - sumr);
-            xst<PERSIST>(&a.ratio_out[(size_t)smp * a.ratio_stride + o], ratio_new);
-            xst<PERSIST>(&a.remain_out[(size_t)smp * a.remain_stride + o], remain_new);
-            if (!PERSIST && a.live_out) {  // owners still live after this level = the owner count of the next pass B
+            a.ratio_out[(size_t)smp * a.ratio_stride + o] = ratio_new;
+            a.remain_out[(size_t)smp * a.remain_stride + o] = remain_new;
+            if (a.live_out) {  // owners still live after this level = the owner count of the next pass B
                 const unsigned long long alive = __ballot(remain_new != 0.f);
                 if (lane == 0) atomicAdd(&a.live_out[(size_t)smp * kLiveRow], (int)__popcll(alive));
             }
-            if (COWN && !PERSIST && a.clist) {
+            if (COWN && a.clist) {
                 // this owner is the (tile * TQ + e)-th live one of its sample == its place in the next pass's candidate list
                 float cx = ox[0], cy = oy[0], cz = oz[0];  // thread e = w * 64 + lane holds owner e in slot r = w
 #pragma unroll
@@ -695,9 +533,9 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             const float rl = pre_ratio;
             const float rL = a.first ? a.multiL : pre_rem;
             const float left = __builtin_fmaxf(0.0f, rL - rl * t0);
-            xst<PERSIST>(rem, left);
+            *rem = left;
             // pass A of the next level: ratioL' = remainL / (1e-9 + sum_l e'*remainR[l])       :37,61
-            if (MODE == PH_CA) xst<PERSIST>(&a.ratio_out[(size_t)smp * a.ratio_stride + o], left / (1e-9f + t1));
+            if (MODE == PH_CA) a.ratio_out[(size_t)smp * a.ratio_stride + o] = left / (1e-9f + t1);
         }
     }
     PCC_ST(6);
@@ -717,7 +555,7 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
     int smp, tile;
     const int bid = (int)blockIdx.x, nwg = (int)gridDim.x;
     if (COWN) {
-        if (a.xcd && a.batch % 8 == 0) {  // samples congruent to the XCD label, tile-major inside the class
+        if (a.batch % 8 == 0) {  // samples congruent to the XCD label, tile-major inside the class
             const int per = a.batch / 8, i = bid / 8;
             smp = (bid % 8) + 8 * (i % per);
             tile = i / per;
@@ -730,14 +568,14 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
         if (a.live_in && tile > 0 && tile * (64 * R / G) >= a.live_in[(size_t)smp * kLiveRow]) return;
     } else {
         int lid = bid;
-        if (a.xcd && nwg > 8) {  // bijective swizzle: the blocks of one residue class get a contiguous run of logical ids
+        if (nwg > 8) {  // bijective swizzle: the blocks of one residue class get a contiguous run of logical ids
             const int q = nwg / 8, r = nwg % 8, x = bid % 8;
             lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
         }
         smp = lid / a.tiles;
         tile = lid - smp * a.tiles;
     }
-    am_phase_body<MODE, R, S, CH, VAR, false, G>(a, smp, tile, smem);
+    am_phase_body<MODE, R, S, CH, VAR, G>(a, smp, tile, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -772,7 +610,7 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
 
     int lid = (int)blockIdx.x;
     const int nwg = (int)gridDim.x;
-    if (a.xcd && nwg > 8) {  // a sample's workgroups share an XCD (see am_phase_kernel)
+    if (nwg > 8) {  // a sample's workgroups share an XCD (see am_phase_kernel)
         const int q = nwg / 8, r = nwg % 8, x = lid % 8;
         lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + lid / 8;
     }
@@ -1151,71 +989,6 @@ __global__ __launch_bounds__(64 * kNNWaves) void nn_sorted_kernel(NNSortedArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Persistent schedule (experimental, off by default -- see the measurement note at its launch site): ONE launch runs
-// all 19 passes.  The measured fixed cost of a pass launch (dispatch, prologue latency, drain) is 10.5 us -- a third
-// of the forward once the exact-zero work is skipped.  Here a workgroup keeps
-// its tile for the whole recurrence and the 16 workgroups of a sample meet at a sample-local barrier between passes:
-// the vectors they exchange (ratioL, ratioR, remainR) are stored and loaded with agent-scope (sc1) accesses, every
-// storing wave drains its stores (s_waitcnt vmcnt(0)) before the workgroup barrier, then one lane bumps the sample's
-// counter and polls it (cdna_hip_programming.md Guideline 16, counter form; no cache-wide fences).  All workgroups
-// must be co-resident: the host launches at most as many as fit (LDS allows two 512-thread workgroups per CU) and
-// splits larger batches into consecutive launches; spins are bounded and raise an error word instead of hanging.
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sample_barrier(unsigned *ctr, unsigned target, unsigned *err, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 stores have left the CU
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 22)) {  // ~1 s: a workgroup of this sample never arrived (not co-resident?)
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
-
-template <int R, int S, int CH>
-__global__ __launch_bounds__(64 * S) void am_persistent_kernel(Sched sc, unsigned *counters, unsigned *err, int tiles,
-                                                                int smp0) {
-    __shared__ __attribute__((aligned(16))) float smem[PhaseLds<2, R, S, CH>::floats];
-    const int smp = smp0 + (int)(blockIdx.x / tiles);
-    const int tile = (int)(blockIdx.x % tiles);
-    const int nph = sched_phases();
-    unsigned long long t0 = sc.dbg ? __builtin_amdgcn_s_memrealtime() : 0;
-    for (int p = 0; p < nph; p++) {
-        int mode, var;
-        const PhaseArgs a = build_phase(sc, p, &mode, &var);
-        if (mode == PH_A) {
-            if (var == V_CULL) am_phase_body<PH_A, R, S, CH, V_CULL, true>(a, smp, tile, smem);
-            else am_phase_body<PH_A, R, S, CH, V_PLAIN, true>(a, smp, tile, smem);
-        } else if (mode == PH_B) {
-            if (var == V_CULL) am_phase_body<PH_B, R, S, CH, V_CULL, true>(a, smp, tile, smem);
-            else if (var == V_COWN) am_phase_body<PH_B, R, S, CH, V_COWN, true>(a, smp, tile, smem);
-            else am_phase_body<PH_B, R, S, CH, V_PLAIN, true>(a, smp, tile, smem);
-        } else if (mode == PH_CA) {
-            if (var == V_CULL) am_phase_body<PH_CA, R, S, CH, V_CULL, true>(a, smp, tile, smem);
-            else if (var == V_CCAND) am_phase_body<PH_CA, R, S, CH, V_CCAND, true>(a, smp, tile, smem);
-            else am_phase_body<PH_CA, R, S, CH, V_PLAIN, true>(a, smp, tile, smem);
-        } else {
-            if (var == V_CCAND) am_phase_body<PH_C, R, S, CH, V_CCAND, true>(a, smp, tile, smem);
-            else am_phase_body<PH_C, R, S, CH, V_PLAIN, true>(a, smp, tile, smem);
-        }
-        unsigned long long t1 = 0;
-        if (sc.dbg && blockIdx.x == 0 && threadIdx.x == 0) t1 = __builtin_amdgcn_s_memrealtime();
-        if (p + 1 < nph) sample_barrier(counters + smp, (unsigned)tiles * (unsigned)(p + 1), err, threadIdx.x);
-        if (sc.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
-            const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
-            sc.dbg[40 + p] = (int)(((t1 - t0) << 16) | ((t2 - t1) & 0xffff));  // body | barrier, 10 ns units
-            t0 = t2;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Spatial sort: one workgroup per (sample, cloud) orders the points along a 30-bit Hilbert curve with a
 // bitonic sort of (code << 32 | index) keys in LDS and writes the sorted SoA coordinates, the inverse
 // permutation (rank) and one bounding box per 16 consecutive sorted points.  Clouds too large for the LDS
@@ -1268,8 +1041,6 @@ struct SortArgs {  // one entry per cloud; blockIdx.y selects it
     int *perm[2];      // sorted position -> original index (inverse of rank)
     float4 *aos[2];    // optional [b][n]: (x, y, z, original index as bits) per sorted point (nn_sorted_kernel)
     float *box[2];
-    float *box64[2];
-    int nb64[2];
     // zero-fill riding along (replaces two memset launches): the two workgroups of a sample clear one region each
     float *zero[2];
     long long zero_stride[2], zero_count[2];  // per-sample stride and length in floats (multiples of 4)
@@ -1340,7 +1111,6 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     int *pm = a.perm[which] + (size_t)smp * n;
     float4 *ao = a.aos[which] ? a.aos[which] + (size_t)smp * n : nullptr;
     float *bx = a.box[which] + (size_t)smp * nb * 8;
-    float *bx64 = a.box64[which] + (size_t)smp * a.nb64[which] * 8;
     int idx_bits = 10;
     while ((1 << idx_bits) < npad) idx_bits++;  // npad >= 1024
     const unsigned idx_mask = (1u << idx_bits) - 1;
@@ -1433,21 +1203,6 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
             dst[0] = make_float4(l0, l1, l2, 0.f);
             dst[1] = make_float4(h0, h1, h2, 0.f);
         }
-        // a wave holds 64 consecutive sorted points: two more butterfly steps give the owner-group box
-#pragma unroll
-        for (int off = kBox; off < 64; off <<= 1) {
-            l0 = fminf(l0, __shfl_xor(l0, off, 64));
-            l1 = fminf(l1, __shfl_xor(l1, off, 64));
-            l2 = fminf(l2, __shfl_xor(l2, off, 64));
-            h0 = fmaxf(h0, __shfl_xor(h0, off, 64));
-            h1 = fmaxf(h1, __shfl_xor(h1, off, 64));
-            h2 = fmaxf(h2, __shfl_xor(h2, off, 64));
-        }
-        if ((s & 63) == 0 && s / 64 < a.nb64[which]) {
-            float4 *dst = reinterpret_cast<float4 *>(bx64 + (size_t)(s / 64) * 8);
-            dst[0] = make_float4(l0, l1, l2, 0.f);
-            dst[1] = make_float4(h0, h1, h2, 0.f);
-        }
     }
 }
 
@@ -1459,10 +1214,7 @@ __global__ __launch_bounds__(256) void am_unpermute_kernel(int n, int m, int n4,
                                                             const float *__restrict__ rem_sorted,
                                                             const int *__restrict__ rank1,
                                                             const int *__restrict__ rank2,
-                                                            const unsigned *__restrict__ err,
                                                             float *__restrict__ lv, float *__restrict__ temp) {
-    // a sample barrier of the persistent kernel timed out: poison the outputs instead of returning garbage
-    const float poison = (err && *err) ? __builtin_nanf("") : 0.f;
     // sorted-space rows are [ratioL (n4) | ratioR (m4)] (16-byte aligned halves); outputs are dense [n | m]
     const int smp = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1474,7 +1226,7 @@ __global__ __launch_bounds__(256) void am_unpermute_kernel(int n, int m, int n4,
     float last = 0.f;
 #pragma unroll
     for (int l = 0; l < kLevels; l++) {
-        last = src[(size_t)l * nm4 + s] + poison;
+        last = src[(size_t)l * nm4 + s];
         dst[(size_t)l * nm + i] = last;
     }
     // remain row: remainL (n4) | remainR ping (m4) | pong (m4); the nine passes B leave the final remainR in pong
@@ -2224,17 +1976,6 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
 // ---- host side -------------------------------------------------------------------------------------
 constexpr int kPhCH = 2048;
 
-// Workgroup shape: R owners per lane x S candidate slices (waves).  One wave can issue a VALU
-// instruction only every 4 cycles while a SIMD retires one every 2, so a phase needs >= 2 (better 4)
-// waves per SIMD = 2048-4096 waves on 256 CUs; R is spent only once the chip is full (each LDS
-// broadcast read is then amortised over R owners).
-static int phase_cfg_override() {
-    static const int v = [] {
-        const char *e = std::getenv("PCC_AM_CFG");
-        return e ? std::atoi(e) : 0;
-    }();
-    return v;
-}
 static bool cull_enabled() {  // PCC_AM_NOCULL=1 disables every work-skipping variant (A/B measurements)
     static const bool v = [] {
         const char *e = std::getenv("PCC_AM_NOCULL");
@@ -2260,21 +2001,13 @@ template <int MODE, int R, int S, int G = 1>
 int launch_phase_rs(PhaseArgs a, int b, int var, hipStream_t st, const char *what) {
     a.tiles = pcc::ceil_div(a.n_own, 64 * R / G);
     a.batch = b;
-    static const int xcd_on = [] {
-        const char *e = std::getenv("PCC_AM_NOXCD");
-        return (e && e[0] == '1') ? 0 : 1;
-    }();
-    a.xcd = xcd_on;
     const long long grid = (long long)b * a.tiles;
     if (grid > 0x7fffffffLL) return pcc::invalid("approxmatch: grid too large");
     {
         pcc::ProfScope prof(phase_name<MODE>(a.level), st);
         const dim3 g((unsigned)grid), blk(64 * S);
         // only the combinations the schedule uses are instantiated
-        if (var == V_CULL) hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, V_CULL>), g, blk, 0, st, a);
-        else if (var == V_CCAND && (MODE == PH_CA || MODE == PH_C))
-            hipLaunchKernelGGL((am_phase_kernel<(MODE == PH_CA || MODE == PH_C) ? MODE : PH_C, R, S, kPhCH, V_CCAND>), g, blk, 0, st, a);
-        else if (var == V_CLIST && (MODE == PH_CA || MODE == PH_C))
+        if (var == V_CLIST && (MODE == PH_CA || MODE == PH_C))
             hipLaunchKernelGGL((am_phase_kernel<(MODE == PH_CA || MODE == PH_C) ? MODE : PH_C, R, S, kPhCH, V_CLIST>), g, blk, 0, st, a);
         else if (var == V_COWN && MODE == PH_B)
             hipLaunchKernelGGL((am_phase_kernel<PH_B, (G > 1 ? 1 : R), S, kPhCH, V_COWN, G>), g, blk, 0, st, a);
@@ -2287,11 +2020,6 @@ template <int MODE>
 int launch_fine(PhaseArgs a, int b, hipStream_t st, const char *what) {
     a.tiles = pcc::ceil_div(a.n_own, 64);
     a.batch = b;
-    static const int xcd_on = [] {
-        const char *e = std::getenv("PCC_AM_NOXCD");
-        return (e && e[0] == '1') ? 0 : 1;
-    }();
-    a.xcd = xcd_on;
     const long long grid = (long long)b * a.tiles;
     if (grid > 0x7fffffffLL) return pcc::invalid("approxmatch: grid too large");
     {
@@ -2303,51 +2031,26 @@ int launch_fine(PhaseArgs a, int b, hipStream_t st, const char *what) {
 
 template <int MODE>
 int launch_phase(const PhaseArgs &a, int b, int var, hipStream_t st, const char *what) {
-    // the box-culled passes of the fine levels: 16-owner groups (am_fine_kernel) unless PCC_AM_FINE=0
-    static const int fine_on = [] {
-        const char *e = std::getenv("PCC_AM_FINE");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    if (var == V_CULL && fine_on && MODE != PH_C) return launch_fine<MODE>(a, b, st, what);
-    int cfg = phase_cfg_override();
-    if (cfg == 0) {
-        const long long owners = (long long)b * a.n_own;
-        // waves = owners / (64 R) * S ; aim for >= 4096
-        // (a large batch arrives here as two concurrent half-batch lanes: 32768 owners per launch at B=32, N=2048,
-        // where 128-owner tiles measured 492 us per forward+backward against 509 us for 64-owner tiles)
-        if (owners >= 4LL * 65536) cfg = 48;
-        else if (owners >= 32768) cfg = 28;
-        else cfg = 18;
+    // the box-culled passes of the fine levels: 16-owner groups
+    if (var == V_CULL) return launch_fine<MODE>(a, b, st, what);
+    // Owner compaction packs the live owners into the first tiles; a full tile takes as long as before (just on fewer
+    // CUs), so these launches use the smallest tile (64 owners x 8 waves), and where few owners are left (recon / uniform
+    // clouds: ~25 % live at level 5, 5 % at level 8) an owner is spread over 2 / 4 lanes: the pair loop of a workgroup,
+    // which is the launch's critical path, gets that much shorter (first levels 3 / 4 and 4 / 6: 2-5 us slower)
+    if (var == V_COWN) {
+        if (a.live_in && a.level >= 5) return launch_phase_rs<MODE, 1, 8, 4>(a, b, var, st, what);
+        if (a.live_in && a.level >= 4) return launch_phase_rs<MODE, 1, 8, 2>(a, b, var, st, what);
+        return launch_phase_rs<MODE, 1, 8>(a, b, var, st, what);
     }
-    // Owner compaction packs the live owners into the first tiles; a full tile takes as long as before (just on
-    // fewer CUs), so these launches use the smallest tile (64 owners x 4 waves): the same work per wave as the
-    // default shape, and with a fraction f of the owners live only f of the wave slots are contended.
-    if (var == V_COWN && cfg != 216) {
-        static const int cown_cfg = [] {
-            const char *e = std::getenv("PCC_AM_COWN_CFG");
-            return e ? std::atoi(e) : 18;
-        }();
-        // lane-split owners where few are left (recon / uniform clouds: ~25 % live at level 5, 5 % at level 8): the
-        // pair loop of a workgroup, which is the launch's critical path, gets G times shorter
-        static const int g_from[2] = {[] { const char *e = std::getenv("PCC_AM_G2_FROM"); return e ? std::atoi(e) : 4; }(),
-                                      [] { const char *e = std::getenv("PCC_AM_G4_FROM"); return e ? std::atoi(e) : 5; }()};
-        if (MODE == PH_B && cown_cfg == 18 && a.live_in) {
-            if (a.level >= g_from[1]) return launch_phase_rs<MODE, 1, 8, 4>(a, b, var, st, what);
-            if (a.level >= g_from[0]) return launch_phase_rs<MODE, 1, 8, 2>(a, b, var, st, what);
-        }
-        switch (cown_cfg) {
-        case 116: return launch_phase_rs<MODE, 1, 16>(a, b, var, st, what);
-        case 18: return launch_phase_rs<MODE, 1, 8>(a, b, var, st, what);
-        case 28: return launch_phase_rs<MODE, 2, 8>(a, b, var, st, what);
-        default: return launch_phase_rs<MODE, 1, 4>(a, b, var, st, what);
-        }
-    }
-    switch (cfg) {
-    case 48: return launch_phase_rs<MODE, 4, 8>(a, b, var, st, what);
-    case 28: return launch_phase_rs<MODE, 2, 8>(a, b, var, st, what);
-    case 216: return launch_phase_rs<MODE, 2, 16>(a, b, var, st, what);
-    default: return launch_phase_rs<MODE, 1, 8>(a, b, var, st, what);
-    }
+    // Workgroup shape: R owners per lane x S candidate slices (waves).  One wave can issue a VALU instruction only every
+    // 4 cycles while a SIMD retires one every 2, so a phase needs >= 2 (better 4) waves per SIMD = 2048-4096 waves on
+    // 256 CUs; R is spent only once the chip is full (each LDS broadcast read is then amortised over R owners).
+    // (A large batch arrives here as two concurrent half-batch lanes: 32768 owners per launch at B=32, N=2048, where
+    // 128-owner tiles measured 492 us per forward+backward against 509 us for 64-owner tiles.)
+    const long long owners = (long long)b * a.n_own;
+    if (owners >= 4LL * 65536) return launch_phase_rs<MODE, 4, 8>(a, b, var, st, what);
+    if (owners >= 32768) return launch_phase_rs<MODE, 2, 8>(a, b, var, st, what);
+    return launch_phase_rs<MODE, 1, 8>(a, b, var, st, what);
 }
 
 struct StreamBuf {  // stream-ordered scratch from the library's private pool (pcc::ws_malloc / ws_free)
@@ -2372,16 +2075,14 @@ size_t cost_parts(int n, int m) { return (size_t)pcc::ceil_div(n, kMatKT) * pcc:
 
 // Workspace carve (bytes, every section 16-byte aligned).
 struct WsLayout {
-    int n4, m4, nb1, nb2, nb64_1, nb64_2;
-    size_t soa1, soa2, rank1, rank2, perm1, perm2, box1, box2, box64_1, box64_2, rem, lv, lv_orig, cpart, sync, clist, clist_cnt, live_cnt, aos1, aos2, total;
+    int n4, m4, nb1, nb2;
+    size_t soa1, soa2, rank1, rank2, perm1, perm2, box1, box2, rem, lv, lv_orig, cpart, clist, clist_cnt, live_cnt, aos1, aos2, total;
     WsLayout(int b, int n, int m) {
         auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
         n4 = (n + 3) & ~3;
         m4 = (m + 3) & ~3;
         nb1 = pcc::ceil_div(n, kBox);
         nb2 = pcc::ceil_div(m, kBox);
-        nb64_1 = pcc::ceil_div(n, 64);
-        nb64_2 = pcc::ceil_div(m, 64);
         size_t o = 0;
         soa1 = o; o = up(o + (size_t)b * 3 * n4 * 4);
         soa2 = o; o = up(o + (size_t)b * 3 * m4 * 4);
@@ -2391,13 +2092,10 @@ struct WsLayout {
         perm2 = o; o = up(o + (size_t)b * m * 4);
         box1 = o; o = up(o + (size_t)b * nb1 * 8 * 4);
         box2 = o; o = up(o + (size_t)b * nb2 * 8 * 4);
-        box64_1 = o; o = up(o + (size_t)b * nb64_1 * 8 * 4);
-        box64_2 = o; o = up(o + (size_t)b * nb64_2 * 8 * 4);
         rem = o; o = up(o + (size_t)b * ((size_t)n4 + 2 * (size_t)m4) * 4);    // sorted space: remainL | remainR x2
         lv = o; o = up(o + (size_t)b * kLevels * ((size_t)n4 + m4) * 4);      // sorted space, padded halves
         lv_orig = o; o = up(o + (size_t)b * kLevels * ((size_t)n + m) * 4);
         cpart = o; o = up(o + (size_t)b * cost_parts(n, m) * 4);
-        sync = o; o = up(o + ((size_t)b + 1) * 4);   // per-sample barrier counters + error word (persistent kernel)
         clist = o; o = up(o + (size_t)b * 5 * m4 * 4);   // dense candidate list handed from pass B to pass C/A
         clist_cnt = o; o = up(o + (size_t)b * 4);
         live_cnt = o; o = up(o + (size_t)b * kLiveRow * 4);
@@ -2408,7 +2106,7 @@ struct WsLayout {
 };
 
 int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const float *xyz2, float *soa1, float *soa2,
-                int *rank1, int *rank2, int *perm1, int *perm2, float *box1, float *box2, float *box64_1, float *box64_2, float *rem, float *lv,
+                int *rank1, int *rank2, int *perm1, int *perm2, float *box1, float *box2, float *rem, float *lv,
                 int *live_cnt, float4 *aos1, float4 *aos2, hipStream_t st) {
     SortArgs a{};
     a.live_cnt = live_cnt;
@@ -2433,7 +2131,6 @@ int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const
     a.n4[0] = L.n4; a.n4[1] = L.m4; a.nb[0] = L.nb1; a.nb[1] = L.nb2;
     a.xyz[0] = xyz1; a.xyz[1] = xyz2; a.soa[0] = soa1; a.soa[1] = soa2;
     a.rank[0] = rank1; a.rank[1] = rank2; a.perm[0] = perm1; a.perm[1] = perm2; a.box[0] = box1; a.box[1] = box2;
-    a.box64[0] = box64_1; a.box64[1] = box64_2; a.nb64[0] = L.nb64_1; a.nb64[1] = L.nb64_2;
     pcc::ProfScope prof("am_sort_kernel", st);
     const dim3 grid(b, 2);
     switch (slots) {
@@ -2450,7 +2147,7 @@ int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const
 // while the first half runs on the caller's stream, so that one half's kernels fill the launch / drain bubbles of
 // the other's (each launch is a chain link of ~20 us with 4-8 us of fixed cost).  Fork and join are events on the
 // caller's stream: for the caller the call still is "enqueue on `stream`, no host synchronisation".
-constexpr int kMaxLanes = 4;
+constexpr int kMaxLanes = 2;
 hipStream_t side_stream(int which) {  // which = 0 .. kMaxLanes - 2
     static std::mutex mu;
     static hipStream_t streams[64][kMaxLanes - 1] = {};
@@ -2504,7 +2201,7 @@ struct ForkJoin {  // side waits for everything enqueued on main so far; at scop
 // Sort + the 19 passes: leaves the nine (ratioL | ratioR) level rows and remainL | remainR in the workspace, in the
 // Hilbert-sorted index space.
 int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const WsLayout &L, char *base, hipStream_t st,
-               bool *persist_out, const std::function<int(int, int, hipStream_t)> &lane_tail = nullptr,
+               const std::function<int(int, int, hipStream_t)> &lane_tail = nullptr,
                const std::function<int(int, int, hipStream_t)> &after_sort = nullptr) {
     const LevelConsts lc = make_levels();
     float multiL, multiR;  // approxmatch.cu:6-12 (integer division)
@@ -2513,10 +2210,6 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
     const long long nm4 = (long long)L.n4 + L.m4;  // sorted-space level row: ratioL (n4) | ratioR (m4)
     const long long rs = (long long)L.n4 + 2LL * L.m4;  // remain row: remainL (n4) | remainR ping (m4) | pong (m4)
 
-    static const float cut_scale = [] {  // debugging aid: PCC_AM_CUTSCALE < 1 skips more than is exact
-        const char *e = std::getenv("PCC_AM_CUTSCALE");
-        return e ? (float)std::atof(e) : 1.0f;
-    }();
     static int *dbg_counters = [] {
         int *p = nullptr;
         const char *e = std::getenv("PCC_AM_DEBUG");
@@ -2529,39 +2222,6 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         return (e && e[0] == '1') ? 1 : 0;
     }();
 
-    // Persistent schedule (one launch for the 19 passes) when the whole batch group can be co-resident and fills the
-    // chip; otherwise one launch per pass.
-    constexpr int kPR = 2, kPS = 8;  // workgroup shape of the persistent kernel (128 owners x 8 waves)
-    const int tiles = std::max(pcc::ceil_div(n, 64 * kPR), pcc::ceil_div(m, 64 * kPR));
-    int resident = 0;
-    {
-        static const int per_cu = [] {
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, am_persistent_kernel<kPR, kPS, kPhCH>, 64 * kPS, 0) != hipSuccess) nb = 0;
-            return nb;
-        }();
-        static const int cus = [] {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-            return v;
-        }();
-        resident = per_cu * cus;
-    }
-    // Measured on MI355X (B=32, N=2048): the persistent schedule is SLOWER than one launch per pass (0.97 ms vs
-    // 0.60 ms): the sc1 hand-off adds ~2 us of memory-side latency to every staging, the workgroups of a sample
-    // wait 10-18 us per pass for their slowest member, and the workgroups parked at a barrier poll while the live
-    // tiles of the owner-compacted passes still run.  It stays available (PCC_AM_PERSIST=1, parity-tested) as the
-    // starting point for the next attempt; the default is one launch per pass.
-    static const int persist_mode = [] {
-        const char *e = std::getenv("PCC_AM_PERSIST");
-        return e ? std::atoi(e) : 0;
-    }();
-    const int group = resident > 0 ? resident / tiles : 0;  // samples per persistent launch
-    const bool use_persist = persist_mode == 1 && group >= 1;
-    static const bool clist_enabled = [] {  // PCC_AM_NOCLIST=1: pass C/A compacts its candidates itself (A/B measurements)
-        const char *e = std::getenv("PCC_AM_NOCLIST");
-        return !(e && e[0] == '1');
-    }();
     static const bool split_enabled = [] {  // PCC_AM_NOSPLIT=1: everything on the caller's stream (A/B measurements)
         const char *e = std::getenv("PCC_AM_NOSPLIT");
         return !(e && e[0] == '1');
@@ -2577,13 +2237,8 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
     };
     Lane lanes[kMaxLanes];
     int nlanes = 1;
-    static const int want_lanes = [] {  // PCC_AM_LANES=2..4 (A/B measurements); default 2
-        const char *e = std::getenv("PCC_AM_LANES");
-        const int v = e ? std::atoi(e) : 2;
-        return v < 2 ? 2 : v > kMaxLanes ? kMaxLanes : v;
-    }();
     hipStream_t side = nullptr;
-    if (!use_persist && split_enabled && !dbg_counters && b >= 8 && (long long)b * std::max(n, m) >= 32768) {
+    if (split_enabled && !dbg_counters && b >= 8 && (long long)b * std::max(n, m) >= 32768) {
         // not while the caller's stream is being captured into a graph: the capture stays a single-stream chain
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
@@ -2593,36 +2248,32 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         if (cap == hipStreamCaptureStatusNone) side = side_stream(0);
     }
     ForkJoin fj(st, side);
-    ForkJoin fj2(st, fj.ok && want_lanes >= 3 ? side_stream(1) : nullptr);
-    ForkJoin fj3(st, fj2.ok && want_lanes >= 4 ? side_stream(2) : nullptr);
-    if (fj.ok) nlanes = 2 + (fj2.ok ? 1 : 0) + (fj3.ok ? 1 : 0);
+    if (fj.ok) nlanes = 2;  // (3 and 4 lanes measured 7-9 % slower: more dependent chains only cost more dispatches)
     for (int l = 0; l < nlanes; l++) {
         Lane &ln = lanes[l];
         ln.s0 = (int)((long long)b * l / nlanes);
         ln.bc = (int)((long long)b * (l + 1) / nlanes) - ln.s0;
-        ln.st = l == 0 ? st : l == 1 ? fj.side : l == 2 ? fj2.side : fj3.side;
+        ln.st = l == 0 ? st : fj.side;
         const size_t s0 = (size_t)ln.s0;
         Sched &sc = ln.sc;
         sc = Sched{};
-        sc.n = n; sc.m = m; sc.n4 = L.n4; sc.m4 = L.m4; sc.nb1 = L.nb1; sc.nb2 = L.nb2; sc.nb64_1 = L.nb64_1; sc.nb64_2 = L.nb64_2;
+        sc.n = n; sc.m = m; sc.n4 = L.n4; sc.m4 = L.m4; sc.nb1 = L.nb1; sc.nb2 = L.nb2;
         sc.soa1 = reinterpret_cast<float *>(base + L.soa1) + s0 * 3 * L.n4;
         sc.soa2 = reinterpret_cast<float *>(base + L.soa2) + s0 * 3 * L.m4;
         sc.box1 = reinterpret_cast<float *>(base + L.box1) + s0 * L.nb1 * 8;
         sc.box2 = reinterpret_cast<float *>(base + L.box2) + s0 * L.nb2 * 8;
-        sc.box64_1 = reinterpret_cast<float *>(base + L.box64_1) + s0 * L.nb64_1 * 8;
-        sc.box64_2 = reinterpret_cast<float *>(base + L.box64_2) + s0 * L.nb64_2 * 8;
         sc.rem = reinterpret_cast<float *>(base + L.rem) + s0 * rs;
         sc.lv = reinterpret_cast<float *>(base + L.lv) + s0 * kLevels * nm4;
-        sc.multiL = multiL; sc.multiR = multiR; sc.cut_scale = cut_scale;
+        sc.multiL = multiL; sc.multiR = multiR;
         sc.skip = cull_enabled() ? 1 : 0;
         sc.lc = lc;
         sc.dbg = l == 0 ? dbg_counters : nullptr;
         sc.dbg_counts = dbg_counts;
-        if (!use_persist && clist_enabled) {
+        {
             sc.clist = reinterpret_cast<float *>(base + L.clist) + s0 * 5 * L.m4;
             sc.clist_cnt = reinterpret_cast<int *>(base + L.clist_cnt) + s0;
         }
-        if (!use_persist && sc.skip) sc.live_cnt = reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow;
+        if (sc.skip) sc.live_cnt = reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow;
     }
     int rc = PCC_OK;
     for (int l = 0; l < nlanes && !rc; l++) {
@@ -2632,8 +2283,7 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
                          const_cast<float *>(ln.sc.soa2), reinterpret_cast<int *>(base + L.rank1) + s0 * n,
                          reinterpret_cast<int *>(base + L.rank2) + s0 * m, reinterpret_cast<int *>(base + L.perm1) + s0 * n,
                          reinterpret_cast<int *>(base + L.perm2) + s0 * m, const_cast<float *>(ln.sc.box1),
-                         const_cast<float *>(ln.sc.box2), const_cast<float *>(ln.sc.box64_1),
-                         const_cast<float *>(ln.sc.box64_2), ln.sc.rem, ln.sc.lv,
+                         const_cast<float *>(ln.sc.box2), ln.sc.rem, ln.sc.lv,
                          reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow,
                          after_sort ? reinterpret_cast<float4 *>(base + L.aos1) + s0 * n : nullptr,
                          after_sort ? reinterpret_cast<float4 *>(base + L.aos2) + s0 * m : nullptr, ln.st);
@@ -2642,37 +2292,15 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
     }
     if (rc) return rc;
 
-    if (use_persist) {
-        const Sched &sc = lanes[0].sc;
-        unsigned *counters = reinterpret_cast<unsigned *>(base + L.sync);
-        if (hipMemsetAsync(counters, 0, ((size_t)b + 1) * sizeof(unsigned), st) != hipSuccess)
-            return pcc::invalid("approxmatch: memset failed");
-        for (int s0 = 0; s0 < b; s0 += group) {
-            const int gb = std::min(group, b - s0);
-            pcc::ProfScope prof("am_persistent_kernel", st);
-            hipLaunchKernelGGL((am_persistent_kernel<kPR, kPS, kPhCH>), dim3((unsigned)(gb * tiles)), dim3(64 * kPS), 0, st, sc,
-                               counters, counters + b, tiles, s0);
-        }
-        rc = pcc::check_launch("approxmatch(persistent)");
-        if (rc) return rc;
-    } else {
+    {
         // pass p of every lane is enqueued before pass p+1 of any: the streams advance together
         pcc::ProfScope seq0("am_phase_sequence", lanes[0].st, true);
         pcc::ProfScope seq1("am_phase_sequence", lanes[nlanes > 1 ? 1 : 0].st, true, nlanes >= 2);
-        pcc::ProfScope seq2("am_phase_sequence", lanes[nlanes > 2 ? 2 : 0].st, true, nlanes >= 3);
-        pcc::ProfScope seq3("am_phase_sequence", lanes[nlanes > 3 ? 3 : 0].st, true, nlanes >= 4);
         for (int p = 0; p < sched_phases() && !rc; p++) {
             for (int l = 0; l < nlanes && !rc; l++) {
                 const Lane &ln = lanes[l];
                 int mode, var;
                 const PhaseArgs a = build_phase(ln.sc, p, &mode, &var);
-                // pass C of level 2 + pass A of level 3: the (16 x 16) boxes still drop half of the pairs at level 3's
-                // radius, more than compacting away the exhausted candidates does (PCC_AM_FINE_CA2=0: the latter)
-                static const int fine_ca2 = [] {
-                    const char *e = std::getenv("PCC_AM_FINE_CA2");
-                    return (e && e[0] == '0') ? 0 : 1;
-                }();
-                if (fine_ca2 && mode == PH_CA && a.level == 2 && var == V_CCAND) var = V_CULL;
                 switch (mode) {
                 case PH_A: rc = launch_phase<PH_A>(a, ln.bc, var, ln.st, "approxmatch(A)"); break;
                 case PH_B: rc = launch_phase<PH_B>(a, ln.bc, var, ln.st, "approxmatch(B)"); break;
@@ -2706,12 +2334,9 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
                 }
             }
         }
-        std::fprintf(stderr, "\n[pcc dbg] persistent block 0, per pass body/barrier x10ns:");
-        for (int q = 0; q < sched_phases(); q++) std::fprintf(stderr, " %d/%d", (unsigned)h[40 + q] >> 16, h[40 + q] & 0xffff);
         std::fprintf(stderr, "\n");
         (void)hipMemset(dbg_counters, 0, sizeof h);
     }
-    *persist_out = use_persist;
     return PCC_OK;
 }
 
@@ -2721,8 +2346,7 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
     if (workspace_bytes < L.total) return pcc::invalid("approxmatch: workspace too small");
     if (!aligned16(workspace)) return pcc::invalid("approxmatch: workspace must be 16-byte aligned");
     char *base = static_cast<char *>(workspace);
-    bool use_persist = false;
-    int rc = run_levels(b, n, m, xyz1, xyz2, L, base, st, &use_persist);
+    int rc = run_levels(b, n, m, xyz1, xyz2, L, base, st);
     if (rc) return rc;
     int *rank1 = reinterpret_cast<int *>(base + L.rank1), *rank2 = reinterpret_cast<int *>(base + L.rank2);
     float *rem = reinterpret_cast<float *>(base + L.rem);
@@ -2731,7 +2355,7 @@ int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, 
     float *cpart = reinterpret_cast<float *>(base + L.cpart);
     const LevelConsts lc = make_levels();
     hipLaunchKernelGGL(am_unpermute_kernel, dim3(pcc::ceil_div(n + m, 256), b), dim3(256), 0, st, n, m, L.n4, L.m4, lv, rem,
-                       rank1, rank2, use_persist ? reinterpret_cast<const unsigned *>(base + L.sync) + b : nullptr, lv_orig, temp);
+                       rank1, rank2, lv_orig, temp);
     rc = pcc::check_launch("approxmatch(unpermute)");
     if (rc) return rc;
     const dim3 grid(pcc::ceil_div(n, kMatKT), pcc::ceil_div(m, kMatLT), b);
@@ -2768,11 +2392,7 @@ int match_cost_implicit_impl(int b, int n, int m, const float *xyz1, const float
                              float *cost, float *grad1, float *grad2, hipStream_t st,
                              const pcc::ChamferOut *chamfer = nullptr) {
     const WsLayout L(b, n, m);
-    static const int q_cols = [] {  // columns per lane (A/B measurements: PCC_AM_PAIRQ=2|4)
-        const char *e = std::getenv("PCC_AM_PAIRQ");
-        const int v = e ? std::atoi(e) : 4;
-        return v == 2 ? 2 : 4;
-    }();
+    constexpr int q_cols = 4;  // columns per lane of am_pair_kernel (2 measured slower)
     const bool grad = grad1 && grad2;
     const int col_blocks = pcc::ceil_div(n, 64 * q_cols), row_tiles = pcc::ceil_div(m, kPairRT);
     auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -2798,7 +2418,7 @@ int match_cost_implicit_impl(int b, int n, int m, const float *xyz1, const float
         pa.part1 = grad ? reinterpret_cast<float *>(base + part1_off) + o * row_tiles * L.n4 * 3 : nullptr;
         pa.part2 = grad ? reinterpret_cast<float *>(base + part2_off) + o * col_blocks * L.m4 * 3 : nullptr;
         const dim3 grid(col_blocks, row_tiles, bc);
-        if (int rc = q_cols == 2 ? launch_pair<2>(pa, grid, grad, lst) : launch_pair<4>(pa, grid, grad, lst)) return rc;
+        if (int rc = launch_pair<q_cols>(pa, grid, grad, lst)) return rc;
         FinishArgs f{};
         f.parts[0] = row_tiles; f.parts[1] = col_blocks; f.parts[2] = col_blocks * row_tiles;
         f.npts[0] = n; f.npts[1] = m; f.pitch[0] = L.n4; f.pitch[1] = L.m4;
@@ -2849,9 +2469,8 @@ int match_cost_implicit_impl(int b, int n, int m, const float *xyz1, const float
         }
         return pcc::check_launch("chamfer_emd(nearest neighbours)");  // (the loss reduction rides in the finish launch)
     };
-    bool use_persist = false;
-    if (chamfer) return run_levels(b, n, m, xyz1, xyz2, L, base, st, &use_persist, tail, nn_after_sort);
-    return run_levels(b, n, m, xyz1, xyz2, L, base, st, &use_persist, tail);
+    if (chamfer) return run_levels(b, n, m, xyz1, xyz2, L, base, st, tail, nn_after_sort);
+    return run_levels(b, n, m, xyz1, xyz2, L, base, st, tail);
 }
 
 int check_sizes(const char *who, int b, int n, int m) {

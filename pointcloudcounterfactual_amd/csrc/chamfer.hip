@@ -344,21 +344,11 @@ int pcc_nndistance(int b, int n, const float *xyz, int m, const float *xyz2, flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     // Queries per lane (R) x candidate split (S): fill 256 CUs with >= 2 waves per SIMD first, then
     // spend registers on R (each LDS broadcast read is amortised over R queries).
-    static const int cfg = [] {
-        const char *e = std::getenv("PCC_NN_CFG");
-        return e ? std::atoi(e) : 0;
-    }();
+    // (measured at B=32, N=2048: 4 queries per lane x 4 waves is the fastest of {1,2,4,8} x {4,8})
     const long long queries = (long long)b * ((long long)n + m);
-    int pick = cfg;
-    if (pick == 0) pick = queries >= 256LL * 64 * 8 ? 44 : (queries >= 256LL * 64 * 2 ? 24 : 14);
-    switch (pick) {
-    case 14: return launch_fwd<1, 4>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, st);
-    case 24: return launch_fwd<2, 4>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, st);
-    case 28: return launch_fwd<2, 8>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, st);
-    case 48: return launch_fwd<4, 8>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, st);
-    case 84: return launch_fwd<8, 4>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, st);
-    default: return launch_fwd<4, 4>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, st);
-    }
+    if (queries >= 256LL * 64 * 8) return launch_fwd<4, 4>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, st);
+    if (queries >= 256LL * 64 * 2) return launch_fwd<2, 4>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, st);
+    return launch_fwd<1, 4>(b, n, xyz, m, xyz2, result, result_i, result2, result2_i, st);
 }
 
 void nndistance(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,

@@ -245,36 +245,6 @@ def test_against_committed_golden_fixture(cuda, tag):
     np.testing.assert_allclose(gm2.cpu().numpy(), z[f'{tag}_mgrad2'], rtol=1e-5, atol=1e-5 * scale)
 
 
-def test_persistent_schedule_parity(cuda):
-    """The experimental one-launch schedule (PCC_AM_PERSIST=1, read once per process) gives the same cost / mass as the
-    default one-launch-per-pass schedule: run it in a child process and compare through a file."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "from tests.util import pair; from pointcloudcounterfactual_amd import backend\n"
-        "a, c = pair(77, 32, 2048, 2048)\n"
-        "m, t, cost = backend.ApproxMatchCost(torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda())\n"
-        "np.savez(sys.argv[1], cost=cost.cpu().numpy(), mass=m.sum((1, 2)).cpu().numpy(), rem=t[:, :4096].cpu().numpy())\n"
-    ) % root
-    outs = []
-    with tempfile.TemporaryDirectory() as d:
-        for mode in ('0', '1'):
-            f = os.path.join(d, f'p{mode}.npz')
-            env = dict(os.environ, PCC_AM_PERSIST=mode)
-            r = subprocess.run([sys.executable, '-c', code, f], env=env, capture_output=True, text=True, timeout=300)
-            assert r.returncode == 0, r.stderr[-2000:]
-            outs.append(dict(np.load(f)))
-    assert np.isfinite(outs[1]['cost']).all()
-    np.testing.assert_allclose(outs[1]['cost'], outs[0]['cost'], rtol=1e-5)
-    np.testing.assert_allclose(outs[1]['mass'], outs[0]['mass'], rtol=1e-5)
-    np.testing.assert_allclose(outs[1]['rem'], outs[0]['rem'], rtol=0, atol=5e-4)
-
-
 def test_bit_reproducible_run_to_run(cuda):
     """No float atomics on the forward path and fixed-order two-stage reductions: two runs give the same bits
     (the reference's unordered atomics do not).  The Chamfer backward accumulates with LDS float atomics and is
