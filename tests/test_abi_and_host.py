@@ -190,3 +190,31 @@ print("ok")
 '''
     r = subprocess.run(['python', '-c', code], capture_output=True, text=True)
     assert r.returncode == 0 and 'ok' in r.stdout, r.stderr[-2000:]
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`bench.py --gpus N` without a launcher environment must start N ranks itself (reference: src/utils/parallel.py:37-53
+    spawns its ranks): the parent builds a `torch.distributed.run` child command for N processes on 127.0.0.1 and relays
+    its exit code -- checked here without a GPU by intercepting the child process."""
+    import argparse
+    import importlib
+    import subprocess
+    import sys
+
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    def fake_run(cmd, env=None, **_kw):
+        seen['cmd'], seen['env'] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '3', '--warmup', '1', '--via-launcher'])
+    rc = bench.self_launch(argparse.Namespace(gpus=4))
+    assert rc == 7
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nproc-per-node=4' in cmd and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-6:] == ['--gpus', '4', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
