@@ -176,12 +176,13 @@ def matchcostgrad_f64(set1, set2, match):
 _i64p = ctypes.POINTER(ctypes.c_int64)
 
 
-def knn_diff(x, k: int):
-    """Difference-form kNN of x[B,C,N] -> idx[B,N,k] int64 (pykeops_knn formula, neighbour_ops.py:77-82)."""
+def knn_diff(x, k: int, query_stride: int = 1):
+    """Difference-form kNN of x[B,C,N] -> idx[B,N,k] int64 (pykeops_knn formula, neighbour_ops.py:77-82).
+    query_stride > 1: only the rows q % query_stride == 0 are computed (the others stay 0)."""
     x = _f(x)
     b, c, n = x.shape
     idx = np.zeros((b, n, k), np.int64)
-    lib().oracle_knn_diff(b, c, n, int(k), _p(x), _p(idx, _i64p))
+    lib().oracle_knn_diff_strided(b, c, n, int(k), _p(x), _p(idx, _i64p), int(query_stride))
     return idx
 
 

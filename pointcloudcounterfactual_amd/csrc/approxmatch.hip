@@ -909,7 +909,7 @@ __global__ __launch_bounds__(64 * kNNWaves) void nn_sorted_kernel(NNSortedArgs a
                 const float dx = fmaxf(fmaxf(glo.x - hi.x, lo.x - ghi.x), 0.f);
                 const float dy = fmaxf(fmaxf(glo.y - hi.y, lo.y - ghi.y), 0.f);
                 const float dz = fmaxf(fmaxf(glo.z - hi.z, lo.z - ghi.z), 0.f);
-                key[h] = (__float_as_uint(dx * dx + dy * dy + dz * dz) & ~127u) | (unsigned)(lane + 64 * h);
+                key[h] = (__float_as_uint(sq3(dx, dy, dz)) & ~127u) | (unsigned)(lane + 64 * h);  // (the candidates' own chain: monotone)
             }
         }
         // ascending bitonic sort of the 128 keys held by the wave (element lane + 64 h): nearest boxes first
@@ -1036,6 +1036,10 @@ __device__ __forceinline__ unsigned hilbert3(unsigned x0, unsigned x1, unsigned 
 struct SortArgs {  // one entry per cloud; blockIdx.y selects it
     int n[2], n4[2], nb[2], npad[2];
     const float *xyz[2];
+    // input layout: coordinate c of point i of sample s sits at xyz[s*sstride + i*pstride + c*cstride]; channels
+    // >= nch read as 0 (the k-NN graph sorts channels-major clouds of 1..3 channels with the same kernel)
+    long long sstride[2], pstride[2], cstride[2];
+    int nch[2];
     float *soa[2];
     int *rank[2];
     int *perm[2];      // sorted position -> original index (inverse of rank)
@@ -1105,9 +1109,12 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
         const long long cnt4 = a.zero_count[which] / 4;
         for (long long i = tid; i < cnt4; i += T) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float *p = a.xyz[which] + (size_t)smp * n * 3;
-    float *so = a.soa[which] + (size_t)smp * 3 * n4;
-    int *rk = a.rank[which] + (size_t)smp * n;
+    const float *p = a.xyz[which] + (size_t)smp * a.sstride[which];
+    const long long ps = a.pstride[which], cs = a.cstride[which];
+    const int nch = a.nch[which];
+    auto coord = [&](int i, int c) -> float { return c < nch ? p[i * ps + c * cs] : 0.f; };
+    float *so = a.soa[which] ? a.soa[which] + (size_t)smp * 3 * n4 : nullptr;
+    int *rk = a.rank[which] ? a.rank[which] + (size_t)smp * n : nullptr;
     int *pm = a.perm[which] + (size_t)smp * n;
     float4 *ao = a.aos[which] ? a.aos[which] + (size_t)smp * n : nullptr;
     float *bx = a.box[which] + (size_t)smp * nb * 8;
@@ -1121,7 +1128,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
         for (int i = tid; i < n; i += T)
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                const float v = p[i * 3 + c];
+                const float v = coord(i, c);
                 lo[c] = fminf(lo[c], v);
                 hi[c] = fmaxf(hi[c], v);
             }
@@ -1154,9 +1161,9 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
             const int i = tid + kSortT * s;
             key[s] = ~0u;
             if (i < n) {
-                const unsigned qx = (unsigned)fminf(fmaxf((p[i * 3 + 0] - lo[0]) * hi[0], 0.f), 1023.f);
-                const unsigned qy = (unsigned)fminf(fmaxf((p[i * 3 + 1] - lo[1]) * hi[1], 0.f), 1023.f);
-                const unsigned qz = (unsigned)fminf(fmaxf((p[i * 3 + 2] - lo[2]) * hi[2], 0.f), 1023.f);
+                const unsigned qx = (unsigned)fminf(fmaxf((coord(i, 0) - lo[0]) * hi[0], 0.f), 1023.f);
+                const unsigned qy = (unsigned)fminf(fmaxf((coord(i, 1) - lo[1]) * hi[1], 0.f), 1023.f);
+                const unsigned qz = (unsigned)fminf(fmaxf((coord(i, 2) - lo[2]) * hi[2], 0.f), 1023.f);
                 key[s] = ((hilbert3(qx, qy, qz) >> code_shift) << idx_bits) | (unsigned)i;
             }
         }
@@ -1174,14 +1181,14 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
         const bool real = s < n;
         if (real) {
             const int orig = npad ? (int)(lds_keys[s] & idx_mask) : s;
-            x = p[orig * 3 + 0];
-            y = p[orig * 3 + 1];
-            z = p[orig * 3 + 2];
-            rk[orig] = s;
+            x = coord(orig, 0);
+            y = coord(orig, 1);
+            z = coord(orig, 2);
+            if (rk) rk[orig] = s;
             pm[s] = orig;
             if (ao) ao[s] = make_float4(x, y, z, __int_as_float(orig));
         }
-        if (s < n4) {
+        if (so && s < n4) {
             so[s] = x;
             so[n4 + s] = y;
             so[2 * n4 + s] = z;
@@ -2105,6 +2112,17 @@ struct WsLayout {
     }
 };
 
+void launch_sort(const SortArgs &a, int slots, dim3 grid, hipStream_t st) {
+    pcc::ProfScope prof("am_sort_kernel", st);
+    switch (slots) {
+    case 4: hipLaunchKernelGGL((am_sort_kernel<4>), grid, dim3(kSortT), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((am_sort_kernel<8>), grid, dim3(kSortT), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((am_sort_kernel<16>), grid, dim3(kSortT), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((am_sort_kernel<32>), grid, dim3(kSortT), 0, st, a); break;
+    default: hipLaunchKernelGGL((am_sort_kernel<64>), grid, dim3(kSortT), 0, st, a); break;
+    }
+}
+
 int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const float *xyz2, float *soa1, float *soa2,
                 int *rank1, int *rank2, int *perm1, int *perm2, float *box1, float *box2, float *rem, float *lv,
                 int *live_cnt, float4 *aos1, float4 *aos2, hipStream_t st) {
@@ -2130,16 +2148,11 @@ int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const
         if (a.npad[w]) a.npad[w] = kSortT * slots;  // one SLOTS instantiation serves both clouds
     a.n4[0] = L.n4; a.n4[1] = L.m4; a.nb[0] = L.nb1; a.nb[1] = L.nb2;
     a.xyz[0] = xyz1; a.xyz[1] = xyz2; a.soa[0] = soa1; a.soa[1] = soa2;
-    a.rank[0] = rank1; a.rank[1] = rank2; a.perm[0] = perm1; a.perm[1] = perm2; a.box[0] = box1; a.box[1] = box2;
-    pcc::ProfScope prof("am_sort_kernel", st);
-    const dim3 grid(b, 2);
-    switch (slots) {
-    case 4: hipLaunchKernelGGL((am_sort_kernel<4>), grid, dim3(kSortT), 0, st, a); break;
-    case 8: hipLaunchKernelGGL((am_sort_kernel<8>), grid, dim3(kSortT), 0, st, a); break;
-    case 16: hipLaunchKernelGGL((am_sort_kernel<16>), grid, dim3(kSortT), 0, st, a); break;
-    case 32: hipLaunchKernelGGL((am_sort_kernel<32>), grid, dim3(kSortT), 0, st, a); break;
-    default: hipLaunchKernelGGL((am_sort_kernel<64>), grid, dim3(kSortT), 0, st, a); break;
+    for (int w = 0; w < 2; w++) {
+        a.sstride[w] = (long long)nn[w] * 3; a.pstride[w] = 3; a.cstride[w] = 1; a.nch[w] = 3;
     }
+    a.rank[0] = rank1; a.rank[1] = rank2; a.perm[0] = perm1; a.perm[1] = perm2; a.box[0] = box1; a.box[1] = box2;
+    launch_sort(a, slots, dim3(b, 2), st);
     return pcc::check_launch("approxmatch(sort)");
 }
 
@@ -2485,6 +2498,20 @@ namespace pcc {
 int match_cost_with_chamfer(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
                             float *grad2, hipStream_t st, const ChamferOut &chamfer) {
     return match_cost_implicit_impl(b, n, m, xyz1, xyz2, nullptr, cost, grad1, grad2, st, &chamfer);
+}
+
+// Hilbert sort of ONE channels-major cloud per sample (x[b][c][n], 1 <= c <= 3) for the k-NN graph (knn.hip): packed
+// sorted rows (x, y, z, original index), the 16-point boxes and the sorted -> original permutation.
+int sort_cloud_cmajor(int b, int c, int n, const float *x, float4 *aos, float *box16, int *perm, hipStream_t st) {
+    SortArgs a{};
+    int npad = 4 * kSortT;
+    while (npad < n) npad <<= 1;
+    if (npad > 64 * kSortT) npad = 0;  // > 16384 points: original order
+    a.n[0] = n; a.npad[0] = npad; a.n4[0] = (n + 3) & ~3; a.nb[0] = pcc::ceil_div(n, kBox);
+    a.xyz[0] = x; a.sstride[0] = (long long)c * n; a.pstride[0] = 1; a.cstride[0] = n; a.nch[0] = c;
+    a.aos[0] = aos; a.box[0] = box16; a.perm[0] = perm;
+    launch_sort(a, npad ? npad / kSortT : 4, dim3(b, 1), st);
+    return pcc::check_launch("knn(sort)");
 }
 }  // namespace pcc
 

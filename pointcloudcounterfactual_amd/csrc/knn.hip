@@ -21,7 +21,9 @@ namespace {
 
 constexpr int kCap = 16;     // FIFO slots per lane
 constexpr int kCH = 2048;    // candidates staged per chunk (small-c kernel)
-constexpr int kTT128 = 1;    // tiles per stage of the 128-channel MFMA instantiation
+constexpr int kSortBoxK = pcc::kSortBox;
+constexpr int kTT128 = 1;
+constexpr int kSortedMaxN = 16384;  // the sort kernel orders up to 16384 points per cloud    // tiles per stage of the 128-channel MFMA instantiation
 
 template <int K, int S>
 struct SmallLayout {
@@ -135,6 +137,229 @@ __global__ __launch_bounds__(64 * S) void knn_small_kernel(int c, int n, int k, 
     }
     __syncthreads();
     if (w == 0 && q_ok) merge_and_store<K, S>(mrg_d, mrg_i, lane, k, indices + ((size_t)smp * n + q) * k, n);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// c <= 3, n <= 16384: search on the Hilbert-sorted cloud.
+// The exhaustive kernel above spends > 90 % of its time in the top-K insertion chains: candidates arrive in index
+// order, so a lane's K-th distance keeps improving all through the scan (K(1 + ln(N/K)) insertions per list, four lists
+// per query).  Here the cloud is first put in Hilbert order with one bounding box per 16 consecutive points (the sort
+// kernel of the approximate EMD, approxmatch.hip).  A WAVE owns one box of 16 consecutive sorted queries and works
+// alone: lane = (query, candidate slice), the four slices of a query take four candidates each of every 16-candidate
+// block and keep their own sorted K-list.
+//   * the candidate blocks of a window are ordered by the distance between their box and the queries' box and visited
+//     nearest first, so the lists fill with near points at once;
+//   * a query's bound: if each of its four slice lists holds at least ceil(k/4) entries <= t, at least k candidates are
+//     <= t, so its k-th distance is <= the largest of the four slices' ceil(k/4)-th entries.  Candidates beyond the bound
+//     are not even buffered; the first block whose box is farther than the largest bound of the 16 queries ends the
+//     walk (exact: nothing that could enter a list, or tie with a lower index, is skipped);
+//   * list entries are 64-bit keys (distance bits : ORIGINAL index): squared distances are non-negative floats, which
+//     order like unsigned integers, so one 64-bit compare is "ascending distance, ties ascending index" although
+//     candidates no longer arrive in index order;
+//   * the four slice lists of a query are merged at the end (LDS, one lane per query).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSW = 4;     // independent waves per workgroup (no barrier; the workgroup only shares the LDS allocation)
+constexpr int kSQ = 16;    // queries per wave = one box of the sort
+constexpr int kSlices = 4; // candidate slices per query
+constexpr unsigned long long kKeyInf = ((unsigned long long)0x7f800000u << 32) | 0x7fffffffull;
+
+// One step of the insertion chain: (slot, carry) <- (min, max) of the two 64-bit keys.  Keys are unique, so once the
+// carry displaces an entry everything behind shifts.  One v_cmp_lt_u64 and four v_cndmask_b32 on ITS mask (written as
+// asm: the compiler turns the two selects into separate unsigned min / max, i.e. two of the slow 64-bit compares).
+__device__ __forceinline__ void ce_step(unsigned long long &slot, unsigned long long &carry) {
+    const unsigned long long m = __ballot(carry < slot);
+    const unsigned sl = (unsigned)slot, sh = (unsigned)(slot >> 32), cl = (unsigned)carry, ch = (unsigned)(carry >> 32);
+    unsigned nsl, nsh, ncl, nch;
+    // (s_nop: a VALU-written SGPR pair needs two wait states before a VALU reads it as a mask)
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %4, %6, %8\n\tv_cndmask_b32_e64 %1, %5, %7, %8\n\t"
+        "v_cndmask_b32_e64 %2, %6, %4, %8\n\tv_cndmask_b32_e64 %3, %7, %5, %8"
+        : "=&v"(nsl), "=&v"(nsh), "=&v"(ncl), "=&v"(nch)
+        : "v"(sl), "v"(sh), "v"(cl), "v"(ch), "s"(m));
+    slot = ((unsigned long long)nsh << 32) | nsl;
+    carry = ((unsigned long long)nch << 32) | ncl;
+}
+
+struct KnnSortedArgs {
+    int n, nb, batch, k;
+    const float4 *aos;   // [b][n] (x, y, z, original index) per sorted point (+ padding, see pcc_knn)
+    const float *box;    // [b][nb][8]
+    const int *perm;     // [b][n]
+    int64_t *out;        // [b][n][k] in the caller's point order
+};
+
+// K = list slots (>= k), KPREV = the next smaller instantiation (k > KPREV)
+template <int K, int KPREV>
+__global__ __launch_bounds__(64 * kSW) void knn_sorted_kernel(KnnSortedArgs a) {
+    // per wave: FIFO [kCap][64] x (distance, index), reused as the merge area [slice][K][16] x key
+    constexpr int kWaveWords = (2 * kCap * 64) > (kSlices * K * kSQ * 2) ? (2 * kCap * 64) : (kSlices * K * kSQ * 2);
+    __shared__ __attribute__((aligned(8))) unsigned smem[kSW * kWaveWords];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gw = (int)blockIdx.x * kSW + w;  // global wave = (sample, box)
+    const int smp = gw / a.nb, grp = gw - smp * a.nb;
+    if (smp >= a.batch) return;  // (whole wave; the kernel has no barrier)
+    unsigned *wbase = smem + w * kWaveWords;
+    float *buf_d = reinterpret_cast<float *>(wbase);
+    int *buf_i = reinterpret_cast<int *>(wbase + kCap * 64);
+    const int n = a.n, k = a.k;
+    const int ql = lane & (kSQ - 1), cs = lane >> 4;
+    const float4 *C = a.aos + (size_t)smp * n;
+    const int qs = min(grp * kSQ + ql, n - 1);
+    const float4 me = C[qs];
+    const float4 *gb = reinterpret_cast<const float4 *>(a.box + ((size_t)smp * a.nb + grp) * 8);
+    const float4 glo = gb[0], ghi = gb[1];
+
+    // ascending; the list lives in the LAST k slots (the first K - k hold key 0, which nothing displaces), so that the
+    // k-th entry is the static register pair key[K - 1]
+    unsigned long long key[K];
+#pragma unroll
+    for (int s = 0; s < K; s++) key[s] = s < K - k ? 0ull : kKeyInf;
+    // the slot whose entry bounds the query's k-th distance (see above): rank ceil(k/4) of the slice when k == K,
+    // otherwise a static slot that has at least that rank for every k in (KPREV, K]
+    constexpr int kTight = K - 1 - (3 * K) / 4, kLoose = K - 1 - (3 * (KPREV + 1)) / 4;
+    unsigned long long thr = kKeyInf;  // buffering threshold: min(own k-th key, the query's bound) at the last flush
+    int cnt = 0;
+    float r = __builtin_inff();        // the largest bound of the 16 queries
+
+    auto flush = [&]() {
+        for (int t = 0; t < kCap; t++) {
+            if (!__any(t < cnt)) break;
+            unsigned long long x = kKeyInf;
+            if (t < cnt) x = ((unsigned long long)__float_as_uint(buf_d[t * 64 + lane]) << 32) | (unsigned)buf_i[t * 64 + lane];
+            if (x < key[K - 1]) {
+#pragma unroll
+                for (int s = 0; s < K; s++) ce_step(key[s], x);
+            }
+        }
+        cnt = 0;
+        // the query's bound over its four slices, then the largest over the 16 queries (distance bits order like ints)
+        int qb = (int)((k == K ? key[kTight] : key[kLoose]) >> 32);
+        qb = max(qb, __shfl_xor(qb, 16, 64));
+        qb = max(qb, __shfl_xor(qb, 32, 64));
+        const unsigned long long bound = ((unsigned long long)(unsigned)qb << 32) | 0x7fffffffull;
+        thr = key[K - 1] < bound ? key[K - 1] : bound;
+        int m = grp * kSQ + ql < n ? qb : 0;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+        r = __int_as_float(__builtin_amdgcn_readfirstlane(m));
+    };
+
+    for (int b0 = 0; b0 < a.nb; b0 += 128) {  // windows of 128 candidate blocks
+        unsigned bkey[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int blk = b0 + lane + 64 * h;
+            bkey[h] = 0xffffffffu;
+            if (blk < a.nb) {
+                const float4 *cb = reinterpret_cast<const float4 *>(a.box + ((size_t)smp * a.nb + blk) * 8);
+                const float4 lo = cb[0], hi = cb[1];
+                const float dx = fmaxf(fmaxf(glo.x - hi.x, lo.x - ghi.x), 0.f);
+                const float dy = fmaxf(fmaxf(glo.y - hi.y, lo.y - ghi.y), 0.f);
+                const float dz = fmaxf(fmaxf(glo.z - hi.z, lo.z - ghi.z), 0.f);
+                // the candidates' own fma chain on the box gaps (every step is monotone: a true lower bound in f32), its 7
+                // lowest mantissa bits replaced by the slot: truncation only lowers the bound
+                const float lb = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                bkey[h] = (__float_as_uint(lb) & ~127u) | (unsigned)(lane + 64 * h);
+            }
+        }
+#pragma unroll
+        for (int kk = 2; kk <= 128; kk <<= 1) {  // ascending bitonic sort of the wave's 128 keys (element lane + 64 h)
+#pragma unroll
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                if (j == 64) {
+                    const unsigned mn = min(bkey[0], bkey[1]), mx = max(bkey[0], bkey[1]);
+                    bkey[0] = mn;
+                    bkey[1] = mx;
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int i = lane + 64 * h;
+                        const unsigned other = (unsigned)__shfl_xor((int)bkey[h], j, 64);
+                        const bool take_min = ((i & j) == 0) == ((i & kk) == 0);
+                        bkey[h] = take_min ? min(bkey[h], other) : max(bkey[h], other);
+                    }
+                }
+            }
+        }
+        const int nwin = min(128, a.nb - b0);
+        auto key_at = [&](int p) -> unsigned {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)bkey[0], p & 63);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)bkey[1], p & 63);
+            return p < 64 ? lo : hi;
+        };
+        // a lane's four candidates of a block are 64 contiguous bytes; the next block's are in flight while this one is
+        // consumed.  Rows past the cloud's end are loaded (the workspace is padded) and never offered.
+        auto load4 = [&](float4 (&v)[4], int c0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = C[c0 + cs * 4 + j];
+        };
+        unsigned bk = key_at(0);
+        float4 cur[4], nxt[4];
+        load4(cur, (b0 + (int)(bk & 127u)) * kSortBoxK);
+        for (int p = 0; p < nwin; p++) {
+            if (__uint_as_float(bk & ~127u) > r) break;  // everything behind is farther still
+            const int c0 = (b0 + (int)(bk & 127u)) * kSortBoxK;
+            const unsigned bk_next = key_at(min(p + 1, nwin - 1));
+            load4(nxt, (b0 + (int)(bk_next & 127u)) * kSortBoxK);
+            if (__any(cnt > kCap - 4)) flush();
+            const int left = n - c0 - cs * 4;  // real candidates from cur[0] on
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float dx = cur[j].x - me.x, dy = cur[j].y - me.y, dz = cur[j].z - me.z;
+                const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                const unsigned long long x = ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(cur[j].w);
+                if (j < left && x < thr) {  // (false for NaN distances: their bits sort above +inf)
+                    buf_d[cnt * 64 + lane] = d;
+                    buf_i[cnt * 64 + lane] = __float_as_int(cur[j].w);
+                    cnt++;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) cur[j] = nxt[j];
+            if (__any(cnt > 0) && ((p & 7) == 7 || p < 8)) flush();  // fresh bounds: every block at first, then every 8th (measured)
+            bk = bk_next;
+        }
+    }
+    flush();
+
+    // merge the four slice lists of every query: [slice][slot][query] keys in the wave's LDS region (the FIFO is drained)
+    unsigned long long *mk = reinterpret_cast<unsigned long long *>(wbase);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < K; s++) mk[(cs * K + s) * kSQ + ql] = key[s];
+    __builtin_amdgcn_wave_barrier();
+    if (cs == 0 && grp * kSQ + ql < n) {
+        int64_t *dst = a.out + ((size_t)smp * n + a.perm[(size_t)smp * n + qs]) * k;
+        int pos[kSlices];
+        unsigned long long h[kSlices];
+#pragma unroll
+        for (int s = 0; s < kSlices; s++) {
+            pos[s] = K - k;
+            h[s] = mk[(s * K + (K - k)) * kSQ + ql];
+        }
+        for (int o = 0; o < k; o++) {
+            int best = 0;
+            unsigned long long bv = h[0];
+#pragma unroll
+            for (int s = 1; s < kSlices; s++) {
+                const bool lt = h[s] < bv;
+                bv = lt ? h[s] : bv;
+                best = lt ? s : best;
+            }
+            // (the lists can run short only when distances are NaN: never emit an index outside the cloud)
+            dst[o] = (int64_t)min((int)(bv & 0xffffffffull), n - 1);
+            int np = 0;
+#pragma unroll
+            for (int s = 0; s < kSlices; s++) np = best == s ? pos[s] + 1 : np;
+            const unsigned long long nh = np < K ? mk[(best * K + np) * kSQ + ql] : kKeyInf;
+#pragma unroll
+            for (int s = 0; s < kSlices; s++) {
+                const bool sel = best == s;
+                pos[s] = sel ? np : pos[s];
+                h[s] = sel ? nh : h[s];
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -310,6 +535,13 @@ int launch_small(int b, int c, int n, int k, const float *x, int64_t *indices, h
     return PCC_OK;
 }
 
+template <int K, int KPREV>
+void launch_sorted(const KnnSortedArgs &a, hipStream_t st) {
+    pcc::ProfScope prof("knn_sorted_kernel", st);
+    const int waves = a.batch * a.nb;
+    hipLaunchKernelGGL((knn_sorted_kernel<K, KPREV>), dim3(pcc::ceil_div(waves, kSW)), dim3(64 * kSW), 0, st, a);
+}
+
 template <int K>
 int launch_mfma(int b, int c, int n, int k, const float *x, const float *sq, int64_t *indices, hipStream_t st) {
     pcc::ProfScope prof("knn_mfma_kernel", st);
@@ -345,7 +577,37 @@ extern "C" int pcc_knn(int b, int c, int n, int k, const float *x, int64_t *indi
     if (b > 65535) return pcc::invalid("knn: batch too large");
     if (!x || !indices) return pcc::invalid("knn: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (c <= 3) {
+    if (c <= 3 && n <= kSortedMaxN) {
+        // sorted search: workspace = packed sorted rows | boxes | permutation
+        const int nb = pcc::ceil_div(n, kSortBoxK);
+        // (+256: the search loads whole 16-row blocks; the last block of the last sample may run past the cloud)
+        const size_t aos_b = (size_t)b * n * 16 + 256, box_b = (size_t)b * nb * 32;
+        SqBuf ws(st);
+        if (pcc::ws_malloc(reinterpret_cast<void **>(&ws.p), aos_b + box_b + (size_t)b * n * 4, st) != hipSuccess) {
+            ws.p = nullptr;
+            (void)hipGetLastError();
+            pcc::set_error(PCC_ENOMEM, "knn: workspace allocation failed");
+            return PCC_ENOMEM;
+        }
+        char *base = reinterpret_cast<char *>(ws.p);
+        KnnSortedArgs a{};
+        a.n = n; a.nb = nb; a.batch = b; a.k = k;
+        a.aos = reinterpret_cast<const float4 *>(base);
+        a.box = reinterpret_cast<const float *>(base + aos_b);
+        a.perm = reinterpret_cast<const int *>(base + aos_b + box_b);
+        a.out = indices;
+        if (int rc = pcc::sort_cloud_cmajor(b, c, n, x, reinterpret_cast<float4 *>(base), reinterpret_cast<float *>(base + aos_b),
+                                            reinterpret_cast<int *>(base + aos_b + box_b), st))
+            return rc;
+        if (k <= 4) launch_sorted<4, 0>(a, st);
+        else if (k <= 8) launch_sorted<8, 4>(a, st);
+        else if (k <= 16) launch_sorted<16, 8>(a, st);
+        else if (k <= 20) launch_sorted<20, 16>(a, st);
+        else if (k <= 25) launch_sorted<25, 20>(a, st);
+        else launch_sorted<32, 25>(a, st);
+        return pcc::check_launch("knn(sorted)");
+    }
+    if (c <= 3) {  // clouds too large for the one-workgroup sort: exhaustive scan
         if (k <= 4) launch_small<4>(b, c, n, k, x, indices, st);
         else if (k <= 8) launch_small<8>(b, c, n, k, x, indices, st);
         else if (k <= 16) launch_small<16>(b, c, n, k, x, indices, st);

@@ -68,4 +68,9 @@ struct ChamferOut {
 int match_cost_with_chamfer(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
                             float *grad2, hipStream_t st, const ChamferOut &chamfer);
 
+// Hilbert sort of one channels-major cloud per sample (approxmatch.hip's sort kernel) for the k-NN graph: aos [b][n]
+// (x, y, z, original index as bits), box16 [b][ceil(n/16)][8] (lo xyz, pad, hi xyz, pad), perm [b][n] sorted -> original.
+constexpr int kSortBox = 16;
+int sort_cloud_cmajor(int b, int c, int n, const float *x, float4 *aos, float *box16, int *perm, hipStream_t st);
+
 }  // namespace pcc

@@ -34,6 +34,23 @@ def test_knn_small_c_bit_exact(cuda, oracle_mod, b, c, n, k):
         assert np.array_equal(idx, oracle_mod.knn_diff(x.numpy(), k))
 
 
+@pytest.mark.parametrize('b,c,n,k', [(2, 3, 1000, 5), (2, 3, 777, 10), (1, 3, 3000, 23), (2, 3, 500, 30), (1, 3, 5000, 20),
+                                       (2, 3, 17, 1), (1, 3, 16, 16), (3, 2, 49, 7), (1, 3, 17000, 8)])
+def test_knn_sorted_search_shapes(cuda, oracle_mod, b, c, n, k):
+    """The Hilbert-sorted search (c <= 3, n <= 16384): k between the list sizes, clouds that are not a multiple of the
+    16-point boxes, several 128-box windows (n > 2048), surface-like clouds (points on a sphere, where the walk ends
+    early), and the exhaustive kernel behind it for n > 16384 -- all bit-identical to the oracle's lists."""
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    x = _x(n * 3 + k, b, c, n)
+    if c == 3:
+        x[0] = x[0] / x[0].norm(dim=0, keepdim=True)  # first sample on the unit sphere
+    idx = ops.knn(x.to(cuda), k).cpu().numpy()
+    stride = 1 if n <= 3000 else 7 if n <= 5000 else 37  # (the oracle sorts a whole row per query)
+    exp = oracle_mod.knn_diff(x.numpy(), k, stride)
+    assert np.array_equal(idx[:, ::stride], exp[:, ::stride])
+
+
 def test_knn_ties_ascending_index(cuda, oracle_mod):
     from pointcloudcounterfactual_amd import neighbour_ops as ops
 

@@ -1,0 +1,24 @@
+"""k-NN graph timings (c <= 3 sorted search and the MFMA kernel) on Gaussian and on surface-like clouds."""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointcloudcounterfactual_amd import neighbour_ops as ops
+dev = torch.device('cuda:0')
+def ev(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3
+B, N = 32, 2048
+torch.manual_seed(0)
+g = torch.randn(B, 3, N, device=dev)
+sph = torch.nn.functional.normalize(torch.randn(B, 3, N, device=dev), dim=1)
+for name, x in (('gauss', g), ('sphere', sph)):
+    for k in (25, 20, 4):
+        print(f'knn c=3 k={k} {name}: {ev(lambda: ops.hip_knn(x, k)):.1f} us')
+if len(sys.argv) > 1:
+    for c in (64, 128):
+        x = torch.randn(B, c, N, device=dev)
+        print(f'knn c={c} k=25: {ev(lambda: ops.hip_knn(x, 25)):.1f} us')
