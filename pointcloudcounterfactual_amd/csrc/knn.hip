@@ -1,9 +1,11 @@
 // k-nearest-neighbour graph for gfx950 (MI355X), wave64.
 //
 // Replaces knn / pykeops_knn (reference src/utils/neighbour_ops.py:63-82: a PyKeOps argKmin over a lazy
-// (B,N,N) squared-distance tensor) -- PyKeOps has no ROCm backend.  Two kernels:
-//   * knn_small_kernel (c <= 3): exact difference-form distances on the f32 VALU, the formula the GPU
-//     reference evaluates (pykeops_square_distance, :35-40).  A lane owns one query; the candidate cloud sits
+// (B,N,N) squared-distance tensor) -- PyKeOps has no ROCm backend.  Three kernels:
+//   * knn_sorted_kernel (c <= 3, n <= 16384): exact difference-form distances on the f32 VALU, the formula the GPU
+//     reference evaluates (pykeops_square_distance, :35-40), on the Hilbert-sorted cloud: only the candidate boxes
+//     that can still hold one of a query's k nearest are visited (see the kernel).
+//   * knn_small_kernel (c <= 3, larger clouds): the same distances, exhaustive.  A lane owns one query; the candidate cloud sits
 //     in LDS as SoA rows (x is already channels-major, so staging is a straight coalesced copy); S waves
 //     scan disjoint candidate ranges; per-lane buffered top-K (topk.hpp); the S sorted lists are merged
 //     with strict '<' in range order, so equal distances come out in ascending index order.
