@@ -27,23 +27,25 @@ struct TopK {
             i[s] = 0x7fffffff;
         }
     }
-    // Insert (x,id) keeping the list sorted; the displaced tail falls off.  Strict '<' for the NEW
-    // element (an equal distance that arrived earlier stays in front); once an element has been displaced
-    // everything behind it shifts unconditionally, so displaced elements keep their relative order too.
+    // Insert (x,id) keeping the list sorted; the displaced tail falls off.  Strict '<' for the NEW element (an equal
+    // distance that arrived earlier stays in front); once an element has been displaced everything behind it shifts
+    // unconditionally, so displaced elements keep their relative order too (equal distances inside the list).  The
+    // distances need no select: the slot keeps the smaller value and the larger one travels on -- a chain of single
+    // v_max_f32 -- and only the indices follow the compare.  Distances in the list are never NaN (offers compare '<'
+    // against the threshold first).
     __device__ __forceinline__ void insert(float x, int id) {
         bool shifting = false;
 #pragma unroll
         for (int s = 0; s < K; s++) {
             const bool lt = shifting || (x < d[s]);
             shifting = lt;
-            const float nd = lt ? x : d[s];
-            const float cx = lt ? d[s] : x;
+            // one instruction each, the slot updated in place (fminf / fmaxf would first canonicalise both operands)
+            float nx;
+            asm("v_max_f32 %1, %2, %0\n\tv_min_f32 %0, %2, %0" : "+v"(d[s]), "=&v"(nx) : "v"(x));
+            x = nx;
             const int ni = lt ? id : i[s];
-            const int ci = lt ? i[s] : id;
-            d[s] = nd;
+            id = lt ? i[s] : id;
             i[s] = ni;
-            x = cx;
-            id = ci;
         }
     }
     __device__ __forceinline__ float worst() const { return d[K - 1]; }
