@@ -51,6 +51,31 @@ def test_knn_sorted_search_shapes(cuda, oracle_mod, b, c, n, k):
     assert np.array_equal(idx[:, ::stride], exp[:, ::stride])
 
 
+def test_knn_degenerate_clouds(cuda, oracle_mod):
+    """All points identical (every distance ties: the lists are 0..k-1 for every query), a single point, and a cloud with
+    NaN / inf coordinates (a NaN distance never enters a list; no index outside the cloud is ever emitted)."""
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    same = torch.full((2, 3, 100), 0.25)
+    idx = ops.knn(same.to(cuda), 10).cpu().numpy()
+    assert (idx == np.arange(10)[None, None, :]).all()
+    one = torch.rand(3, 3, 1)
+    assert (ops.knn(one.to(cuda), 1).cpu().numpy() == 0).all()
+    x = _x(5, 2, 3, 200)
+    x[0, 1, 17] = float('nan')
+    x[1, 0, 3] = float('inf')
+    idx = ops.knn(x.to(cuda), 8).cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < 200
+    ok = np.ones(200, bool)
+    ok[17] = False
+    # queries other than the NaN point: the NaN candidate is never chosen, the rest as the oracle on the cloud without it
+    assert not (idx[0, ok] == 17).any()
+    clean = torch.cat([x[0, :, :17], x[0, :, 18:]], dim=1)[None]
+    ref = oracle_mod.knn_diff(clean.numpy(), 8)[0]
+    ref = ref + (ref >= 17)  # indices of the cloud with point 17 removed -> original numbering
+    assert np.array_equal(idx[0, ok], ref)
+
+
 def test_knn_ties_ascending_index(cuda, oracle_mod):
     from pointcloudcounterfactual_amd import neighbour_ops as ops
 
