@@ -567,11 +567,7 @@ __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
         // stays: it carries the zeros of the exhausted owners into the output buffer)
         if (a.live_in && tile > 0 && tile * (64 * R / G) >= a.live_in[(size_t)smp * kLiveRow]) return;
     } else {
-        int lid = bid;
-        if (nwg > 8) {  // bijective swizzle: the blocks of one residue class get a contiguous run of logical ids
-            const int q = nwg / 8, r = nwg % 8, x = bid % 8;
-            lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
-        }
+        const int lid = pcc::xcd_contiguous(bid, nwg);  // the blocks of one residue class get a contiguous run of logical ids
         smp = lid / a.tiles;
         tile = lid - smp * a.tiles;
     }
@@ -608,12 +604,7 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
     __shared__ unsigned char need[NBLK];
     __shared__ int wave_cnt[kFineS];
 
-    int lid = (int)blockIdx.x;
-    const int nwg = (int)gridDim.x;
-    if (nwg > 8) {  // a sample's workgroups share an XCD (see am_phase_kernel)
-        const int q = nwg / 8, r = nwg % 8, x = lid % 8;
-        lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + lid / 8;
-    }
+    const int lid = pcc::xcd_contiguous((int)blockIdx.x, (int)gridDim.x);  // a sample's workgroups share an XCD (see am_phase_kernel)
     const int smp = lid / a.tiles;
     const int tile = lid - smp * a.tiles;
     const int tid = threadIdx.x, lane = tid & 63;

@@ -46,7 +46,10 @@ __global__ __launch_bounds__(64 * S) void nn_fwd_kernel(int b, int n, const floa
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // Which direction / sample / query tile is this workgroup?  (wave-uniform)
-    int bid = blockIdx.x;
+    // XCD affinity (cdna_hip_programming.md T1): blocks with equal blockIdx % 8 share an XCD and its L2.  Every workgroup
+    // of a (direction, sample) scans the same candidate cloud, so the blocks of one residue class get a contiguous run of
+    // logical ids (bijective): a cloud crosses the fabric once per launch instead of once per XCD (a pure speed choice).
+    int bid = pcc::xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
     const int dir0 = b * tiles_n;
     const float *Q, *C;
     float *out_d;
@@ -206,7 +209,9 @@ __global__ __launch_bounds__(256) void nn_bwd_range_kernel(int n, const float *_
                                                             const float *__restrict__ add2,
                                                             const float *__restrict__ add_scale, int add_stride) {
     extern __shared__ __attribute__((aligned(16))) float acc[];
-    const int smp = blockIdx.y, p = blockIdx.x;
+    // (a sample's P workgroups gather from the same two clouds: one XCD, see nn_fwd_kernel)
+    const int lid = pcc::xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int smp = lid / P, p = lid - smp * P;
     const int tid = threadIdx.x, T = 256;
     const int j0 = (int)((long long)n * p / P), j1 = (int)((long long)n * (p + 1) / P);
     const int k0 = (int)((long long)m * p / P), k1 = (int)((long long)m * (p + 1) / P);
@@ -304,11 +309,11 @@ int launch_bwd(int b, int n, const float *xyz1, int m, const float *xyz2, const 
     P = std::min<long long>(P, std::max(1, std::min(n, m) / 64));
     const long long lds_min = ((long long)n + m) * 12 / (48 * 1024) + 1;
     P = std::max(P, lds_min);
-    if (P > 65535) return pcc::invalid("nndistancegrad: clouds too large");
+    if (P * b > 0x7fffffffLL) return pcc::invalid("nndistancegrad: clouds too large");
     const size_t lds = ((size_t)pcc::ceil_div(n, (int)P) + pcc::ceil_div(m, (int)P) + 2) * 3 * sizeof(float);
     {
         pcc::ProfScope prof("nn_bwd_range_kernel", st);
-        hipLaunchKernelGGL(nn_bwd_range_kernel, dim3((unsigned)P, (unsigned)b), dim3(256), lds, st, n, xyz1, m, xyz2,
+        hipLaunchKernelGGL(nn_bwd_range_kernel, dim3((unsigned)(P * b)), dim3(256), lds, st, n, xyz1, m, xyz2,
                            grad_dist1, idx1, grad_dist2, idx2, grad_xyz1, grad_xyz2, (int)P, gloss, mean, gloss_stride,
                            add1, add2, add_scale, add_stride);
     }

@@ -68,6 +68,15 @@ struct ChamferOut {
 int match_cost_with_chamfer(int b, int n, int m, const float *xyz1, const float *xyz2, float *cost, float *grad1,
                             float *grad2, hipStream_t st, const ChamferOut &chamfer);
 
+// Logical block id such that the blocks of one XCD (equal blockIdx % 8: the dispatcher deals workgroups round-robin over the
+// 8 XCDs) hold a contiguous run of logical ids.  Bijective on [0, nwg); consecutive logical ids -- the workgroups of one
+// sample -- then share an L2.  Placement is a speed matter only: nothing may depend on it.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nwg) {
+    if (nwg <= 8) return bid;
+    const int q = nwg / 8, r = nwg % 8, x = bid % 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+}
+
 // Hilbert sort of one channels-major cloud per sample (approxmatch.hip's sort kernel) for the k-NN graph: aos [b][n]
 // (x, y, z, original index as bits), box16 [b][ceil(n/16)][8] (lo xyz, pad, hi xyz, pad), perm [b][n] sorted -> original.
 constexpr int kSortBox = 16;
