@@ -22,3 +22,12 @@ if len(sys.argv) > 1:
     for c in (64, 128):
         x = torch.randn(B, c, N, device=dev)
         print(f'knn c={c} k=25: {ev(lambda: ops.hip_knn(x, 25)):.1f} us')
+    # the reference's CPU formula (torch_knn, neighbour_ops.py:53-74) run by stock PyTorch on the GPU: expanded-form
+    # distances through bmm, then topk -- what a user gets without this library
+    def torch_knn(x, k):
+        inner = -2 * torch.bmm(x.transpose(2, 1), x)
+        xx = (x ** 2).sum(dim=1, keepdim=True)
+        return (inner + xx + xx.transpose(2, 1)).topk(k, dim=-1, largest=False)[1]
+    for c in (3, 64, 128):
+        x = torch.randn(B, c, N, device=dev)
+        print(f'stock torch bmm+topk c={c} k=25: {ev(lambda: torch_knn(x, 25), iters=5, warm=2):.1f} us')
