@@ -76,6 +76,32 @@ def test_knn_degenerate_clouds(cuda, oracle_mod):
     assert np.array_equal(idx[0, ok], ref)
 
 
+def test_knn_sorted_search_random_sweep(cuda, oracle_mod):
+    """Seeded sweep of the sorted search over awkward sizes: clouds around the 16-point box and 2048-point window
+    boundaries, every list size and k in between, 1-3 channels, Gaussian / uniform / planar / clustered clouds."""
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    rng = np.random.default_rng(77)
+    sizes = [1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 255, 1000, 2047, 2048, 2049, 2063, 2065, 4097]
+    for trial in range(40):
+        n = int(sizes[trial % len(sizes)] if trial < 20 else rng.integers(1, 2600))
+        k = int(min(n, rng.integers(1, 33)))
+        b = int(rng.integers(1, 4))
+        c = int(rng.integers(1, 4))
+        kind = trial % 4
+        x = rng.standard_normal((b, c, n)).astype(np.float32)
+        if kind == 1:
+            x = rng.random((b, c, n)).astype(np.float32)
+        elif kind == 2 and c == 3:
+            x[:, 2] = 0.0  # planar
+        elif kind == 3:
+            x = (x * 0.01 + rng.integers(0, 3, (b, c, n))).astype(np.float32)  # tight clusters on a lattice
+        idx = ops.knn(torch.from_numpy(x).to(cuda), k).cpu().numpy()
+        stride = 1 if n <= 2600 else 5
+        exp = oracle_mod.knn_diff(x, k, stride)
+        assert np.array_equal(idx[:, ::stride], exp[:, ::stride]), (trial, b, c, n, k, kind)
+
+
 def test_knn_ties_ascending_index(cuda, oracle_mod):
     from pointcloudcounterfactual_amd import neighbour_ops as ops
 
