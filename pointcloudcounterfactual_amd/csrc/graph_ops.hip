@@ -17,6 +17,34 @@ namespace {
 // the Python layer documents that indices must lie in [0, n).
 __device__ __forceinline__ int nbr(long long v, int n, int self) { return (unsigned long long)v < (unsigned long long)n ? (int)v : self; }
 
+// The k neighbours of the 64 points a wave works on, for the per-point modes (max / sum / min-max over k).  A lane that
+// walks its own row of the [n][k] int64 list reads 8 bytes every 8k bytes: 64 cache lines per wave-load, and every channel
+// block of the sample repeats it.  Instead the wave copies its 64 rows -- one contiguous run of 64k entries -- with
+// coalesced loads into LDS as 16-bit indices (n <= 40960 here; 0xffff = "not a valid index": the point itself), and the
+// lanes read their rows from there.  Wave-local: no workgroup barrier.  Without room in LDS (stage == nullptr) the rows
+// are read from global memory as before.
+struct NbrList {
+    unsigned short *stage;   // this wave's [64][k] staging area, or nullptr
+    const int64_t *ib;       // the sample's [n][k] list
+    int n, k, lane;
+    __device__ __forceinline__ void load(int first_point) {  // the wave's points are first_point .. first_point + 63
+        if (!stage) return;
+        __builtin_amdgcn_wave_barrier();  // (the previous tile's reads are done)
+        const int cnt = max(0, min(64, n - first_point)) * k;
+        const int64_t *src = ib + (size_t)first_point * k;
+        for (int e = lane; e < cnt; e += 64) {
+            const long long v = src[e];
+            stage[e] = (unsigned long long)v < (unsigned long long)n ? (unsigned short)v : (unsigned short)0xffff;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ int at(int i, int j) const {  // neighbour j of point i (this lane's point)
+        if (!stage) return nbr(ib[(size_t)i * k + j], n, i);
+        const int s = stage[lane * k + j];
+        return s == 0xffff ? i : s;
+    }
+};
+
 // Forward: a workgroup owns CB channels of one sample, stages those rows of x in LDS (the gathers then hit
 // LDS instead of 64 different cache lines per wave-instruction) and streams the (n,k) index list.
 //   MODE 0: gather            out[b,c,n,j]  = x[b,c,idx]
@@ -28,8 +56,9 @@ __device__ __forceinline__ int nbr(long long v, int n, int self) { return (unsig
 template <int MODE, int CB>
 __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, const float *__restrict__ x,
                                                            const int64_t *__restrict__ indices, float *__restrict__ out,
-                                                           int32_t *__restrict__ argmax, int64_t *__restrict__ tsel) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];  // [CB][n]
+                                                           int32_t *__restrict__ argmax, int64_t *__restrict__ tsel,
+                                                           int stage_off) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];  // [CB][n] (+ index staging, see NbrList)
     const int smp = blockIdx.y, c0 = blockIdx.x * CB;
     const int tid = threadIdx.x, T = 1024;
     const size_t nk = (size_t)n * k;
@@ -38,8 +67,14 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
     for (int i = tid; i < cb * n; i += T) rows[i] = xb[i];
     __syncthreads();
     const int64_t *ib = indices + (size_t)smp * nk;
+    NbrList nl;
+    nl.ib = ib; nl.n = n; nl.k = k; nl.lane = tid & 63;
+    nl.stage = stage_off ? reinterpret_cast<unsigned short *>(rows + stage_off) + (size_t)(tid >> 6) * 64 * k : nullptr;
     if (MODE == 3 || MODE == 4) {
-        for (int i = tid; i < n; i += T) {
+        for (int base = 0; base < n; base += T) {
+            const int i = base + tid;
+            nl.load(base + (tid & ~63));
+            if (i >= n) continue;
             float acc[CB], lo[CB];
             int tb[CB], tl[CB];
 #pragma unroll
@@ -49,7 +84,7 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
                 tb[cc] = tl[cc] = 0;
             }
             for (int j = 0; j < k; j++) {
-                const int t = nbr(ib[(size_t)i * k + j], n, i);
+                const int t = nl.at(i, j);
 #pragma unroll
                 for (int cc = 0; cc < CB; cc++) {
                     if (cc < cb) {
@@ -80,7 +115,10 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
             }
         }
     } else if (MODE == 2) {
-        for (int i = tid; i < n; i += T) {
+        for (int base = 0; base < n; base += T) {
+            const int i = base + tid;
+            nl.load(base + (tid & ~63));
+            if (i >= n) continue;
             float best[CB];
             int bj[CB];
 #pragma unroll
@@ -89,7 +127,7 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
                 bj[cc] = 0;
             }
             for (int j = 0; j < k; j++) {
-                const int t = nbr(ib[(size_t)i * k + j], n, i);
+                const int t = nl.at(i, j);
 #pragma unroll
                 for (int cc = 0; cc < CB; cc++) {
                     if (cc < cb) {
@@ -406,8 +444,15 @@ int gather_fwd(int b, int c, int n, int k, const float *x, const int64_t *indice
                hipStream_t st, const char *what, int64_t *tsel = nullptr) {
     int cb = 8;
     while (cb > 1 && (size_t)cb * n * sizeof(float) > 64 * 1024) cb >>= 1;
-    const size_t lds = (size_t)cb * n * sizeof(float);
+    size_t lds = (size_t)cb * n * sizeof(float);
     if (lds > 160 * 1024) return pcc::invalid("graph op: n too large for the LDS row tile");
+    // the per-point modes stage each wave's 64 x k neighbour indices (16 bit) behind the rows when that still fits
+    int stage_off = 0;
+    const size_t rows_pad = (lds + 15) / 16 * 16, stage_bytes = (size_t)16 * 64 * k * sizeof(unsigned short);
+    if (MODE >= 2 && rows_pad + stage_bytes <= 160 * 1024) {
+        stage_off = (int)(rows_pad / sizeof(float));
+        lds = rows_pad + stage_bytes;
+    }
     const dim3 grid(pcc::ceil_div(c, cb), b);
     pcc::ProfScope prof(what, st);
 #define PCC_LAUNCH(CB)                                                                                              \
@@ -415,7 +460,8 @@ int gather_fwd(int b, int c, int n, int k, const float *x, const int64_t *indice
         static bool attr = hipFuncSetAttribute(reinterpret_cast<const void *>(gather_lds_kernel<MODE, CB>),         \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; \
         (void)attr;                                                                                                 \
-        hipLaunchKernelGGL((gather_lds_kernel<MODE, CB>), grid, dim3(1024), lds, st, c, n, k, x, indices, out, argmax, tsel); \
+        hipLaunchKernelGGL((gather_lds_kernel<MODE, CB>), grid, dim3(1024), lds, st, c, n, k, x, indices, out, argmax, tsel, \
+                           stage_off);                                                                              \
     } while (0)
     switch (cb) {
     case 8: PCC_LAUNCH(8); break;
