@@ -400,10 +400,17 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             const float *sw0 = W0_CONST ? nullptr : W0 + q0;
             const float *sw1 = NW == 2 ? W1 + q0 : nullptr;
             for (int i = tid; i < ngroups; i += T) {
-                const float4 vx = sx[i], vy = sy[i], vz = sz[i];
+                float4 vx = sx[i], vy = sy[i], vz = sz[i];
                 float4 v0 = make_float4(a.w0c, a.w0c, a.w0c, a.w0c), v1 = v0;
                 if (!W0_CONST) v0 = *reinterpret_cast<const float4 *>(sw0 + 4 * i);
                 if (NW == 2) v1 = *reinterpret_cast<const float4 *>(sw1 + 4 * i);
+                if (CLIST && i * 4 + 3 >= cnt) {
+                    // the dense list's tail is stale scratch: a padded candidate gets weight 0 below AND finite
+                    // coordinates here (0 * exp2(NaN) would be NaN, not the exact 0 a padded candidate must add)
+                    vx.y = i * 4 + 1 < cnt ? vx.y : 0.f; vx.z = i * 4 + 2 < cnt ? vx.z : 0.f; vx.w = 0.f;
+                    vy.y = i * 4 + 1 < cnt ? vy.y : 0.f; vy.z = i * 4 + 2 < cnt ? vy.z : 0.f; vy.w = 0.f;
+                    vz.y = i * 4 + 1 < cnt ? vz.y : 0.f; vz.z = i * 4 + 2 < cnt ? vz.z : 0.f; vz.w = 0.f;
+                }
                 if ((W0_CONST || CLIST) && i * 4 + 3 >= cnt) {  // padded candidates must weigh 0 (the list's tail is stale)
                     v0.x = i * 4 + 0 < cnt ? v0.x : 0.f;
                     v0.y = i * 4 + 1 < cnt ? v0.y : 0.f;

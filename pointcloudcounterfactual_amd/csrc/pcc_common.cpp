@@ -72,7 +72,15 @@ hipError_t ws_malloc(void **p, size_t bytes, hipStream_t st) {
     if (e != hipSuccess) {
         *p = nullptr;
         (void)hipGetLastError();
+        return e;
     }
+    // PCC_WS_POISON=1 (test runs): every workspace starts as 0xFF bytes -- NaN as a float, -1 as an index -- so a kernel
+    // that reads scratch nobody wrote shows up as a NaN / a fault instead of passing on whatever the pool held before
+    static const bool poison = [] {
+        const char *v = std::getenv("PCC_WS_POISON");
+        return v && v[0] == '1';
+    }();
+    if (poison) (void)hipMemsetAsync(*p, 0xFF, bytes, st);
     return e;
 }
 hipError_t ws_free(void *p, hipStream_t st) { return p ? hipFreeAsync(p, st) : hipSuccess; }

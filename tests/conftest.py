@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# Every library workspace starts as 0xFF bytes (NaN as a float, -1 as an index) while the tests run: a kernel that reads
+# scratch nobody wrote fails a test instead of passing on whatever the memory pool held before.  (This is how the stale
+# tail of the approximate EMD's dense candidate list was found: 0 * exp2(NaN coordinates) is NaN, not 0.)  Read once when
+# the library allocates its first workspace; child processes of the tests inherit it.
+os.environ.setdefault('PCC_WS_POISON', '1')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

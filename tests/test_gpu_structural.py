@@ -445,6 +445,28 @@ def test_two_lane_schedule_equals_single_stream(cuda):
     assert np.array_equal(m1[0].sum(2).cpu().numpy(), z['rowmass'])
 
 
+def test_stale_workspace_does_not_leak_into_results(cuda):
+    """The library's scratch comes from a stream-ordered pool and is not cleared; the suite runs with PCC_WS_POISON=1
+    (conftest.py), which fills every workspace with NaN patterns first.  Results must not depend on it: a call repeated
+    after other library calls have recycled the pool returns the same bits (sizes whose dense candidate lists end in a
+    partial float4 group, the case that once multiplied a stale NaN coordinate by a zero weight)."""
+    import os
+
+    from pointcloudcounterfactual_amd import backend
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    assert os.environ.get('PCC_WS_POISON') == '1'
+    for seed, b, n, m in ((3, 2, 1024, 1024), (4, 3, 777, 1530), (5, 9, 2048, 2048)):
+        a, c = pair(seed, b, n, m, 'uniform')
+        t1, t2 = _dev(a, cuda), _dev(c, cuda)
+        first = [x.clone() for x in backend.MatchCostImplicit(t1, t2, True)]
+        ops.hip_knn(t1.transpose(1, 2).contiguous(), 7)  # other users of the pool in between
+        backend.NNDistance(t1, t2)
+        again = backend.MatchCostImplicit(t1, t2, True)
+        assert all(torch.isfinite(x).all() for x in first)
+        assert all(torch.equal(x, y) for x, y in zip(first, again))
+
+
 def test_package_import_before_torch(cuda):
     """The library must share torch's HIP runtime whatever the import order (``_lib`` imports torch before it loads
     the shared object): a fresh process that imports the package first, as ``__graft_entry__.build()`` followed by

@@ -2,7 +2,8 @@
 import sys, os, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloudcounterfactual_amd import backend
-from pointcloudcounterfactual_amd.losses import chamfer, match_cost
+from pointcloudcounterfactual_amd.losses import chamfer, chamfer_emd, match_cost
+from pointcloudcounterfactual_amd import neighbour_ops as ops
 from emd import emdModule
 dev = torch.device('cuda:0')
 rng = np.random.default_rng(0)
@@ -13,6 +14,15 @@ for it in range(300):
     x = torch.rand(b, n, 3, device=dev, requires_grad=True); y = torch.rand(b, m, 3, device=dev)
     (chamfer(x, y) + match_cost(x, y)).sum().backward()
     assert torch.isfinite(x.grad).all()
+    # encoder primitives on the same changing shapes: sorted k-NN search (c <= 3), staged index rows in the graph kernels
+    k = int(rng.integers(1, min(n, 32) + 1))
+    pts = x.detach().transpose(1, 2).contiguous()
+    idx = ops.hip_knn(pts, k)
+    assert int(idx.min()) >= 0 and int(idx.max()) < n and bool((idx[:, :, 0] == torch.arange(n, device=dev)).all())
+    f = torch.randn(b, 16, n, device=dev)
+    assert torch.isfinite(ops.graph_max_pooling(f, idx, k)).all()
+    lc, le = chamfer_emd(x, y)
+    assert torch.isfinite(lc + le).all()
     if it % 25 == 0:
         a = torch.rand(8, 1024, 3, device=dev); c = torch.rand(8, 1024, 3, device=dev)
         d, _ = emdModule()(a, c, 0.005, 30)
