@@ -78,6 +78,7 @@ enum Phase { PH_A = 0, PH_B = 1, PH_CA = 2, PH_C = 3 };
 constexpr int kDbgInts = 64 + 24 * 19;  // counters + per-phase stamps
 constexpr int kBox = 16;          // points per bounding-box block (sorted order)
 constexpr int kLiveRow = 16;      // ints per sample in the live-owner counters (one per level, padded)
+constexpr int kInfSlot = 13;      // live-counter row, slots 13 / 14: set1 / set2 of the sample holds an infinite coordinate
 constexpr float kZeroExp = 151.f; // exp2(x) == 0 exactly for x <= -150 (below the smallest f32 subnormal)
 
 struct PhaseArgs {
@@ -1101,7 +1102,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     const int which = blockIdx.y;
     const int n = a.n[which], n4 = a.n4[which], nb = a.nb[which], npad = a.npad[which];
     const int smp = blockIdx.x, tid = threadIdx.x, T = kSortT;
-    if (a.live_cnt && which == 0 && threadIdx.x < kLiveRow) a.live_cnt[(size_t)blockIdx.x * kLiveRow + threadIdx.x] = 0;
+    if (a.live_cnt && which == 0 && threadIdx.x < kInfSlot) a.live_cnt[(size_t)blockIdx.x * kLiveRow + threadIdx.x] = 0;
     if (a.zero[which]) {  // fire-and-forget stores, hidden under the sort
         float4 *z = reinterpret_cast<float4 *>(a.zero[which] + (size_t)smp * a.zero_stride[which]);
         const long long cnt4 = a.zero_count[which] / 4;
@@ -1174,6 +1175,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     // sorted SoA rows + inverse permutation; the box of every 16 consecutive sorted points falls out of a
     // 16-lane min/max butterfly on the coordinates the lanes already hold
     const int span = ((max(n4, nb * kBox) + 63) / 64) * 64;
+    int has_inf = 0;
     for (int s = tid; s < span; s += T) {
         float x = 0.f, y = 0.f, z = 0.f;
         const bool real = s < n;
@@ -1182,6 +1184,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
             x = coord(orig, 0);
             y = coord(orig, 1);
             z = coord(orig, 2);
+            has_inf |= (__builtin_isinf(x) || __builtin_isinf(y) || __builtin_isinf(z)) ? 1 : 0;
             if (rk) rk[orig] = s;
             pm[s] = orig;
             if (ao) ao[s] = make_float4(x, y, z, __int_as_float(orig));
@@ -1208,6 +1211,14 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
             dst[0] = make_float4(l0, l1, l2, 0.f);
             dst[1] = make_float4(h0, h1, h2, 0.f);
         }
+    }
+    // An infinite coordinate makes every pair of its point exp(-inf) = 0 -- skipped here as an exact zero -- while the
+    // reference goes on to multiply that 0 by sqrt(inf): its cost and gradients of the sample are NaN (approxmatch.cu:207,
+    // 247-248).  The sample is flagged and the finish kernel reports NaN.  (NaN coordinates need no flag: they reach the
+    // sums through the distances, as in the reference.)
+    if (a.live_cnt) {
+        const int any_inf = __syncthreads_or(has_inf);
+        if (tid == 0) a.live_cnt[(size_t)blockIdx.x * kLiveRow + kInfSlot + which] = any_inf ? 1 : 0;
     }
 }
 
@@ -1927,6 +1938,7 @@ struct FinishArgs {
     const float *ch_d1, *ch_d2;
     float *ch_loss;
     int ch_n, ch_m, ch_mean;
+    const int *flags;  // live-counter rows [b][kLiveRow] (slots kInfSlot, kInfSlot + 1), or null
 };
 __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
     __shared__ float red[256];
@@ -1950,6 +1962,8 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
         if (tid == 0) f.ch_loss[smp] = f.ch_mean ? red2[0] / (float)f.ch_m + red[0] / (float)f.ch_n : red[0] + red2[0];
         return;
     }
+    // a sample with an infinite coordinate: NaN cost and gradients (see am_sort_kernel)
+    const bool poisoned = f.flags && (f.flags[(size_t)smp * kLiveRow + kInfSlot] | f.flags[(size_t)smp * kLiveRow + kInfSlot + 1]);
     if (which == 2) {  // cost[b] = sum of the workgroup partials, fixed order
         if (blockIdx.x) return;
         const int parts = f.parts[2];
@@ -1961,7 +1975,7 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
             if (tid < off) red[tid] += red[tid + off];
             __syncthreads();
         }
-        if (tid == 0) f.out[2][smp] = red[0];
+        if (tid == 0) f.out[2][smp] = poisoned ? __builtin_nanf("") : red[0];
         return;
     }
     if (!f.out[which]) return;
@@ -1975,7 +1989,7 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
     float acc = p[0];
     for (int t = 1; t < parts; t++) acc += p[(size_t)t * pitch * 3];
     const int pt = f.perm[which][(size_t)smp * npts + s];
-    f.out[which][((size_t)smp * npts + pt) * 3 + c] = f.scale ? acc * f.scale[smp] : acc;
+    f.out[which][((size_t)smp * npts + pt) * 3 + c] = poisoned ? __builtin_nanf("") : f.scale ? acc * f.scale[smp] : acc;
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -2440,6 +2454,7 @@ int match_cost_implicit_impl(int b, int n, int m, const float *xyz1, const float
         f.out[0] = grad ? grad1 + o * n * 3 : nullptr;
         f.out[1] = grad ? grad2 + o * m * 3 : nullptr;
         f.out[2] = cost + o;
+        f.flags = reinterpret_cast<const int *>(base + L.live_cnt) + o * kLiveRow;  // (written by this call's sort)
         if (chamfer) {
             f.ch_d1 = chamfer->dist1 + o * n; f.ch_d2 = chamfer->dist2 + o * m; f.ch_loss = chamfer->loss + o;
             f.ch_n = n; f.ch_m = m; f.ch_mean = chamfer->mean;

@@ -467,6 +467,36 @@ def test_stale_workspace_does_not_leak_into_results(cuda):
         assert all(torch.equal(x, y) for x, y in zip(first, again))
 
 
+def test_non_finite_coordinates_follow_the_reference(cuda, oracle_mod):
+    """NaN / infinite coordinates.  The reference has no guard: a NaN coordinate reaches the sums through the distances; an
+    infinite one makes its point's pairs exp(-inf) = 0, which matchcost then multiplies by sqrt(inf) -- NaN cost
+    (approxmatch.cu:207).  The implicit path skips exact zeros, so it flags such a sample and reports NaN cost and
+    gradients for it; the other samples of the batch are untouched.  The NaN patterns of cost (and of grad1 for a NaN
+    input) equal the oracle's."""
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(7, 3, 512, 512, 'recon')
+    base = [x.cpu().numpy() for x in backend.MatchCostImplicit(_dev(a, cuda), _dev(c, cuda), True)]
+    for which, smp, val in ((0, 0, np.nan), (1, 1, np.inf), (0, 2, -np.inf)):
+        x, y = a.copy(), c.copy()
+        (x if which == 0 else y)[smp, 100, 1] = val
+        cost, g1, g2 = [t.cpu().numpy() for t in backend.MatchCostImplicit(_dev(x, cuda), _dev(y, cuda), True)]
+        _m, _t, cost_m = backend.ApproxMatchCost(_dev(x, cuda), _dev(y, cuda))
+        om, _ = oracle_mod.approxmatch(x, y)
+        oc = oracle_mod.matchcost(x, y, om)
+        og1, _og2 = oracle_mod.matchcostgrad(x, y, om)
+        assert np.array_equal(np.isnan(cost), np.isnan(oc)) and np.isnan(cost[smp]), (which, smp, val, cost, oc)
+        assert np.array_equal(np.isnan(cost_m.cpu().numpy()), np.isnan(oc))
+        keep = [s for s in range(3) if s != smp]
+        assert np.array_equal(cost[keep], base[0][keep])
+        assert np.array_equal(g1[keep], base[1][keep]) and np.array_equal(g2[keep], base[2][keep])
+        assert np.isnan(g1[smp]).any() and np.isnan(g2[smp]).any()
+        if np.isnan(val):
+            assert np.array_equal(np.isnan(g1).any(-1), np.isnan(og1).any(-1))
+        else:  # every gradient of the other cloud involves the infinite point (reference: 0 * inf)
+            assert np.isnan((g1 if which == 1 else g2)[smp]).all()
+
+
 def test_package_import_before_torch(cuda):
     """The library must share torch's HIP runtime whatever the import order (``_lib`` imports torch before it loads
     the shared object): a fresh process that imports the package first, as ``__graft_entry__.build()`` followed by
