@@ -153,7 +153,10 @@ int pcc_matchcostgrad_scaled(int b, int n, int m, const float *xyz1, const float
  * sums: no 4*b*n*m-byte tensor is written or read.
  *   cost[b]                     = what pcc_approxmatch + pcc_matchcost return (float summation order differs);
  *   grad1[b,n,3], grad2[b,m,3]  = what pcc_matchcostgrad_scaled returns; pass both or neither (NULL: cost only);
- *   grad_cost[b] or NULL (= 1). */
+ *   grad_cost[b] or NULL (= 1).
+ * Non-finite coordinates: a NaN propagates through the distances as in the reference; a sample with an infinite
+ * coordinate returns NaN cost and NaN gradients (the reference's 0 * sqrt(inf), approxmatch.cu:207,247-248), the other
+ * samples of the batch are unaffected. */
 int pcc_match_cost(int b, int n, int m, const float *xyz1, const float *xyz2, const float *grad_cost, float *cost,
                    float *grad1, float *grad2, pcc_stream_t stream);
 
