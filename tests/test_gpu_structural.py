@@ -497,6 +497,37 @@ def test_non_finite_coordinates_follow_the_reference(cuda, oracle_mod):
             assert np.isnan((g1 if which == 1 else g2)[smp]).all()
 
 
+def test_calls_on_two_caller_streams_at_once(cuda):
+    """Two caller streams enqueue library calls back to back without synchronising in between: both calls fork onto the one
+    internal side stream of the device, draw their scratch from the one pool, and must still return what each returns
+    alone (stream-ordered allocation, fork / join events per call)."""
+    from pointcloudcounterfactual_amd import backend
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    a1, c1 = pair(31, 32, 2048, 2048, 'recon')
+    a2, c2 = pair(32, 16, 1500, 2048, 'uniform')
+    t = [_dev(v, cuda) for v in (a1, c1, a2, c2)]
+    alone = [backend.ChamferEMD(t[0], t[1], True, True), backend.ChamferEMD(t[2], t[3], True, True),
+             ops.hip_knn(t[2].transpose(1, 2).contiguous(), 20)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    pts = t[2].transpose(1, 2).contiguous()
+    outs = [[], [], []]
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            outs[0].append(backend.ChamferEMD(t[0], t[1], True, True))
+        with torch.cuda.stream(s2):
+            outs[1].append(backend.ChamferEMD(t[2], t[3], True, True))
+            outs[2].append(ops.hip_knn(pts, 20))
+    torch.cuda.synchronize()
+    for r in outs[0]:
+        assert all(torch.equal(x, y) for x, y in zip(r, alone[0]) if torch.is_tensor(x))
+    for r in outs[1]:
+        assert all(torch.equal(x, y) for x, y in zip(r, alone[1]) if torch.is_tensor(x))
+    for r in outs[2]:
+        assert torch.equal(r, alone[2])
+
+
 def test_package_import_before_torch(cuda):
     """The library must share torch's HIP runtime whatever the import order (``_lib`` imports torch before it loads
     the shared object): a fresh process that imports the package first, as ``__graft_entry__.build()`` followed by
