@@ -457,6 +457,21 @@ __global__ __launch_bounds__(256, CP >= 128 ? 2 : 1) void knn_mfma_kernel(int c,
         for (int i = 0; i < E; i++) dst[tid + i * T] = pre[i];
         if (tid < TW) tsq[slot * TW + tid] = pre_sq;
     };
+    // The two half-waves keep separate lists for the same query (lane and lane ^ 32).  Each list alone would keep
+    // buffering until ITS K-th distance is beaten; but once both lists hold ceil(K/2) entries <= t, at least K candidates
+    // are <= t, so nothing above t can reach the query's k nearest: after every drain the buffering threshold drops to
+    // the larger of the two lists' ceil(K/2)-th entries (ties at t still pass: the threshold is the next float above t).
+    auto flush_shared = [&]() {
+        tk.flush();
+        const float mine = tk.top.d[(K + 1) / 2 - 1];
+        const float t = fmaxf(mine, __shfl_xor(mine, 32, 64));
+        float up = t;  // next float above t (t is never NaN; +inf stays)
+        if (t < __builtin_inff()) {
+            const int bits = __float_as_int(t);
+            up = t == 0.f ? __int_as_float(1) : __int_as_float(t > 0.f ? bits + 1 : bits - 1);
+        }
+        tk.thr = fminf(tk.thr, up);
+    };
     fetch(0);
     commit(0);
     __syncthreads();
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(256, CP >= 128 ? 2 : 1) void knn_mfma_kernel(int c,
         }
 #pragma unroll
         for (int u = 0; u < TT; u++) {
-            if (tk.must_flush(16)) tk.flush();
+            if (tk.must_flush(16)) flush_shared();
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = u * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // candidate inside the stage
