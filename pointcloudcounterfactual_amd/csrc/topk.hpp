@@ -28,25 +28,25 @@ struct TopK {
         }
     }
     // Insert (x,id) keeping the list sorted; the displaced tail falls off.  Strict '<' for the NEW element (an equal
-    // distance that arrived earlier stays in front); once an element has been displaced everything behind it shifts
-    // unconditionally, so displaced elements keep their relative order too (equal distances inside the list).  The
-    // distances need no select: the slot keeps the smaller value and the larger one travels on -- a chain of single
-    // v_max_f32 -- and only the indices follow the compare.  Distances in the list are never NaN (offers compare '<'
-    // against the threshold first).
+    // distance that arrived earlier stays in front); an entry behind a displaced one shifts whatever its own value, so
+    // displaced entries keep their relative order too (equal distances inside the list).
+    // Every slot is computed from the OLD list, independently of the other slots -- no value is carried from slot to
+    // slot, so the K compares and selects overlap instead of forming one dependent chain (a compare's mask takes tens
+    // of cycles to reach the select that consumes it: tools/cmp_bench.hip):
+    //   d'[s] = median(d[s-1], x, d[s])            (one v_med3_f32: the list is sorted)
+    //   i'[s] = x < d[s-1] ? i[s-1] : x < d[s] ? id : i[s]
+    // Distances in the list are never NaN (offers compare '<' against the threshold first).
     __device__ __forceinline__ void insert(float x, int id) {
-        bool shifting = false;
+        bool lt[K];
 #pragma unroll
-        for (int s = 0; s < K; s++) {
-            const bool lt = shifting || (x < d[s]);
-            shifting = lt;
-            // one instruction each, the slot updated in place (fminf / fmaxf would first canonicalise both operands)
-            float nx;
-            asm("v_max_f32 %1, %2, %0\n\tv_min_f32 %0, %2, %0" : "+v"(d[s]), "=&v"(nx) : "v"(x));
-            x = nx;
-            const int ni = lt ? id : i[s];
-            id = lt ? i[s] : id;
-            i[s] = ni;
+        for (int s = 0; s < K; s++) lt[s] = x < d[s];
+#pragma unroll
+        for (int s = K - 1; s > 0; s--) {  // downwards: slot s - 1 still holds its old value
+            i[s] = lt[s - 1] ? i[s - 1] : (lt[s] ? id : i[s]);
+            d[s] = __builtin_amdgcn_fmed3f(d[s - 1], x, d[s]);
         }
+        i[0] = lt[0] ? id : i[0];
+        d[0] = lt[0] ? x : d[0];
     }
     __device__ __forceinline__ float worst() const { return d[K - 1]; }
 };
