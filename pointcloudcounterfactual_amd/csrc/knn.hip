@@ -218,6 +218,11 @@ __global__ __launch_bounds__(64 * kSW) void knn_sorted_kernel(KnnSortedArgs a) {
     for (int s = 0; s < K; s++) key[s] = s < K - k ? 0ull : kKeyInf;
     // the slot whose entry bounds the query's k-th distance (see above): rank ceil(k/4) of the slice when k == K,
     // otherwise a static slot that has at least that rank for every k in (KPREV, K]
+    // The insertion pass in its carry-free form (every slot from the old list) needs ~30 fewer VGPRs than the chain that
+    // carries the displaced key from slot to slot: at K = 20 that is a fourth wave per SIMD (104 vs 118 us on the surface
+    // clouds), at K <= 8 a few per cent; at K = 16 / 25 / 32 the occupancy is capped elsewhere (VGPRs of the rest, LDS of
+    // the merge) and the carried chain is the faster one (measured: 101 / 139 / 169 us against 108 / 154 / 229).
+    constexpr bool kCarryFree = K <= 8 || K == 20;
     constexpr int kTight = K - 1 - (3 * K) / 4, kLoose = K - 1 - (3 * (KPREV + 1)) / 4;
     unsigned long long thr = kKeyInf;  // buffering threshold: min(own k-th key, the query's bound) at the last flush
     int cnt = 0;
@@ -229,8 +234,18 @@ __global__ __launch_bounds__(64 * kSW) void knn_sorted_kernel(KnnSortedArgs a) {
             unsigned long long x = kKeyInf;
             if (t < cnt) x = ((unsigned long long)__float_as_uint(buf_d[t * 64 + lane]) << 32) | (unsigned)buf_i[t * 64 + lane];
             if (x < key[K - 1]) {
+                if (kCarryFree) {
+                    // every slot from the OLD list: key'[s] = x < key[s-1] ? key[s-1] : x < key[s] ? x : key[s]
+                    bool lt[K];
 #pragma unroll
-                for (int s = 0; s < K; s++) ce_step(key[s], x);
+                    for (int s = 0; s < K; s++) lt[s] = x < key[s];
+#pragma unroll
+                    for (int s = K - 1; s > 0; s--) key[s] = lt[s - 1] ? key[s - 1] : (lt[s] ? x : key[s]);
+                    key[0] = lt[0] ? x : key[0];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < K; s++) ce_step(key[s], x);
+                }
             }
         }
         cnt = 0;
