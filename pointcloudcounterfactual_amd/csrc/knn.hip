@@ -191,9 +191,12 @@ struct KnnSortedArgs {
 
 // K = list slots (>= k), KPREV = the next smaller instantiation (k > KPREV)
 template <int K, int KPREV>
-__global__ __launch_bounds__(64 * kSW) void knn_sorted_kernel(KnnSortedArgs a) {
-    // per wave: FIFO [kCap][64] x (distance, index), reused as the merge area [slice][K][16] x key
-    constexpr int kWaveWords = (2 * kCap * 64) > (kSlices * K * kSQ * 2) ? (2 * kCap * 64) : (kSlices * K * kSQ * 2);
+__global__ __launch_bounds__(64 * kSW, (K <= 25 ? 4 : 1)) void knn_sorted_kernel(KnnSortedArgs a) {  // (<= 128 VGPRs up to K = 25: four waves per SIMD)
+    // per wave: FIFO [kCap][64] x (distance, index), reused as the merge area [slice][K][16] x (distance 4 B | index 2 B:
+    // n <= 16384) -- 6 bytes per entry keep K = 25 under 10 KB per wave, i.e. four waves per SIMD
+    constexpr int kEntries = kSlices * K * kSQ;
+    constexpr int kMergeWords = kEntries + (kEntries + 1) / 2;
+    constexpr int kWaveWords = (2 * kCap * 64) > kMergeWords ? (2 * kCap * 64) : kMergeWords;
     __shared__ __attribute__((aligned(8))) unsigned smem[kSW * kWaveWords];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -219,10 +222,11 @@ __global__ __launch_bounds__(64 * kSW) void knn_sorted_kernel(KnnSortedArgs a) {
     // the slot whose entry bounds the query's k-th distance (see above): rank ceil(k/4) of the slice when k == K,
     // otherwise a static slot that has at least that rank for every k in (KPREV, K]
     // The insertion pass in its carry-free form (every slot from the old list) needs ~30 fewer VGPRs than the chain that
-    // carries the displaced key from slot to slot: at K = 20 that is a fourth wave per SIMD (104 vs 118 us on the surface
-    // clouds), at K <= 8 a few per cent; at K = 16 / 25 / 32 the occupancy is capped elsewhere (VGPRs of the rest, LDS of
-    // the merge) and the carried chain is the faster one (measured: 101 / 139 / 169 us against 108 / 154 / 229).
-    constexpr bool kCarryFree = K <= 8 || K == 20;
+    // carries the displaced key from slot to slot, which decides the occupancy at K = 20 and 25 (four waves per SIMD
+    // together with the 6-byte merge entries; surface clouds: 118 -> 104 us and 139 -> 133 us, Gaussian 231 -> 197 us at
+    // K = 25) and is worth a few per cent at K <= 8; at K = 16 and 32 the carried chain measured faster (90 / 164 us
+    // against 100 / 193) -- there the launch bound alone (128 VGPRs up to K = 25) is what helps (K = 16: 101 -> 90 us).
+    constexpr bool kCarryFree = K <= 8 || K == 20 || K == 25;
     constexpr int kTight = K - 1 - (3 * K) / 4, kLoose = K - 1 - (3 * (KPREV + 1)) / 4;
     unsigned long long thr = kKeyInf;  // buffering threshold: min(own k-th key, the query's bound) at the last flush
     int cnt = 0;
@@ -340,10 +344,19 @@ __global__ __launch_bounds__(64 * kSW) void knn_sorted_kernel(KnnSortedArgs a) {
     flush();
 
     // merge the four slice lists of every query: [slice][slot][query] keys in the wave's LDS region (the FIFO is drained)
-    unsigned long long *mk = reinterpret_cast<unsigned long long *>(wbase);
+    unsigned *md = wbase;                                                        // distance bits
+    unsigned short *mi = reinterpret_cast<unsigned short *>(wbase + kEntries);  // original index (0xffff: the empty-slot sentinel)
+    auto merged_key = [&](int e) -> unsigned long long {
+        const unsigned i16 = mi[e];
+        return ((unsigned long long)md[e] << 32) | (i16 == 0xffffu ? 0x7fffffffu : i16);
+    };
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int s = 0; s < K; s++) mk[(cs * K + s) * kSQ + ql] = key[s];
+    for (int s = 0; s < K; s++) {
+        const unsigned lo = (unsigned)key[s];
+        md[(cs * K + s) * kSQ + ql] = (unsigned)(key[s] >> 32);
+        mi[(cs * K + s) * kSQ + ql] = (unsigned short)(lo == 0x7fffffffu ? 0xffffu : lo);
+    }
     __builtin_amdgcn_wave_barrier();
     if (cs == 0 && grp * kSQ + ql < n) {
         int64_t *dst = a.out + ((size_t)smp * n + a.perm[(size_t)smp * n + qs]) * k;
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(64 * kSW) void knn_sorted_kernel(KnnSortedArgs a) {
 #pragma unroll
         for (int s = 0; s < kSlices; s++) {
             pos[s] = K - k;
-            h[s] = mk[(s * K + (K - k)) * kSQ + ql];
+            h[s] = merged_key((s * K + (K - k)) * kSQ + ql);
         }
         for (int o = 0; o < k; o++) {
             int best = 0;
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(64 * kSW) void knn_sorted_kernel(KnnSortedArgs a) {
             int np = 0;
 #pragma unroll
             for (int s = 0; s < kSlices; s++) np = best == s ? pos[s] + 1 : np;
-            const unsigned long long nh = np < K ? mk[(best * K + np) * kSQ + ql] : kKeyInf;
+            const unsigned long long nh = np < K ? merged_key((best * K + np) * kSQ + ql) : kKeyInf;
 #pragma unroll
             for (int s = 0; s < kSlices; s++) {
                 const bool sel = best == s;
