@@ -187,7 +187,10 @@ __global__ __launch_bounds__(1024) void auction_cluster_kernel(int n, int C, con
                                                                 int smp0, unsigned *__restrict__ host_err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, T = 1024;
-    const int smp = smp0 + (int)(blockIdx.x / C), c = (int)(blockIdx.x % C);
+    // the C workgroups of a sample exchange prices, bids and barrier arrivals through the L2: give them block ids of one
+    // XCD (pcc::xcd_contiguous; a speed choice only -- every shared word is an agent-scope access)
+    const int lid = pcc::xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int smp = smp0 + lid / C, c = lid % C;
     const int j0 = (int)((long long)n * c / C), j1 = (int)((long long)n * (c + 1) / C);
     const int njmax = (n + C - 1) / C + 1;
     float *sx = reinterpret_cast<float *>(smem);
