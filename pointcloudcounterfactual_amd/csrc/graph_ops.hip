@@ -59,7 +59,10 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
                                                            int32_t *__restrict__ argmax, int64_t *__restrict__ tsel,
                                                            int stage_off) {
     extern __shared__ __attribute__((aligned(16))) float rows[];  // [CB][n] (+ index staging, see NbrList)
-    const int smp = blockIdx.y, c0 = blockIdx.x * CB;
+    // one-dimensional launch, sample-major on XCD-contiguous ids: the channel blocks of a sample share an L2 (they all
+    // stream the sample's index list; side by side on eight XCDs each would fetch it over the fabric)
+    const int nblk = (c + CB - 1) / CB, lid = pcc::xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int smp = lid / nblk, c0 = (lid - smp * nblk) * CB;
     const int tid = threadIdx.x, T = 1024;
     const size_t nk = (size_t)n * k;
     const float *xb = x + ((size_t)smp * c + c0) * n;
@@ -216,7 +219,10 @@ __global__ __launch_bounds__(1024) void scatter_lds_kernel(int c, int n, int k, 
                                                             const int32_t *__restrict__ argmax,
                                                             const float *__restrict__ g, float *__restrict__ grad_x) {
     extern __shared__ __attribute__((aligned(16))) float bins[];  // [CB][n]
-    const int smp = blockIdx.y, c0 = blockIdx.x * CB;
+    // one-dimensional launch, sample-major on XCD-contiguous ids: the channel blocks of a sample share an L2 (they all
+    // stream the sample's index list; side by side on eight XCDs each would fetch it over the fabric)
+    const int nblk = (c + CB - 1) / CB, lid = pcc::xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int smp = lid / nblk, c0 = (lid - smp * nblk) * CB;
     const int tid = threadIdx.x, T = 1024;
     const size_t nk = (size_t)n * k;
     const int64_t *ib = indices + (size_t)smp * nk;
@@ -315,7 +321,10 @@ __global__ __launch_bounds__(1024) void nbrsum_bwd_sorted_kernel(int c, int n, i
                                                                   float *__restrict__ grad_x) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // rows [CB][n] | bins [CB][n]
     float *rows = lds, *bins = lds + (size_t)CB * n;
-    const int smp = blockIdx.y, c0 = blockIdx.x * CB;
+    // one-dimensional launch, sample-major on XCD-contiguous ids: the channel blocks of a sample share an L2 (they all
+    // stream the sample's index list; side by side on eight XCDs each would fetch it over the fabric)
+    const int nblk = (c + CB - 1) / CB, lid = pcc::xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int smp = lid / nblk, c0 = (lid - smp * nblk) * CB;
     const int tid = threadIdx.x, T = 1024, lane = tid & 63;
     const size_t nk = (size_t)n * k;
     const unsigned *rb = rev + (size_t)smp * nk;
@@ -453,7 +462,7 @@ int gather_fwd(int b, int c, int n, int k, const float *x, const int64_t *indice
         stage_off = (int)(rows_pad / sizeof(float));
         lds = rows_pad + stage_bytes;
     }
-    const dim3 grid(pcc::ceil_div(c, cb), b);
+    const dim3 grid((unsigned)(pcc::ceil_div(c, cb) * b));
     pcc::ProfScope prof(what, st);
 #define PCC_LAUNCH(CB)                                                                                              \
     do {                                                                                                            \
@@ -481,7 +490,7 @@ int scatter_bwd(int b, int c, int n, int k, const int64_t *indices, const int32_
     while (cb > 1 && (size_t)cb * n * sizeof(float) > 64 * 1024) cb >>= 1;
     const size_t lds = (size_t)cb * n * sizeof(float);
     if (lds > 160 * 1024) return pcc::invalid("graph op backward: n too large for the LDS bins");
-    const dim3 grid(pcc::ceil_div(c, cb), b);
+    const dim3 grid((unsigned)(pcc::ceil_div(c, cb) * b));
     pcc::ProfScope prof(what, st);
 #define PCC_LAUNCH(CB)                                                                                               \
     do {                                                                                                             \
@@ -604,7 +613,7 @@ int pcc_neighbour_sum_bwd(int b, int c, int n, int k, const int64_t *indices, co
         int cb = 4;
         while (cb > 1 && (size_t)2 * cb * n * sizeof(float) > 64 * 1024) cb >>= 1;
         const size_t lds = (size_t)2 * cb * n * sizeof(float);
-        const dim3 grid(pcc::ceil_div(c, cb), b);
+        const dim3 grid((unsigned)(pcc::ceil_div(c, cb) * b));
         {
             pcc::ProfScope prof("nbrsum_bwd_sorted_kernel", st);
 #define PCC_LAUNCH_S(CB)                                                                                                  do {                                                                                                                      static bool attr = [] {                                                                                                   const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(nbrsum_bwd_sorted_kernel<CB>),                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;             if (!ok) (void)hipGetLastError();                                                                                     return ok;                                                                                                        }();                                                                                                                  (void)attr;                                                                                                           hipLaunchKernelGGL((nbrsum_bwd_sorted_kernel<CB>), grid, dim3(1024), lds, st, c, n, k, rev, grad_out, grad_x);     } while (0)
