@@ -528,6 +528,48 @@ def test_calls_on_two_caller_streams_at_once(cuda):
         assert torch.equal(r, alone[2])
 
 
+def test_two_host_threads_call_the_library_at_once(cuda):
+    """ctypes releases the GIL: two Python threads are inside the library's host code at the same time, each on its own
+    stream (the side stream, the pool, the profiling and error state are shared or per-thread).  Results equal the
+    serial ones."""
+    import threading
+
+    from pointcloudcounterfactual_amd import backend
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    a1, c1 = pair(41, 32, 2048, 2048, 'recon')
+    a2, c2 = pair(42, 9, 1000, 1300, 'uniform')
+    t = [_dev(v, cuda) for v in (a1, c1, a2, c2)]
+    pts = t[2].transpose(1, 2).contiguous()
+    want = [backend.ChamferEMD(t[0], t[1], True, True), backend.MatchCostImplicit(t[2], t[3], True), ops.hip_knn(pts, 16)]
+    torch.cuda.synchronize()
+    got = [[], []]
+    errs = []
+
+    def work(which):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(10):
+                    if which == 0:
+                        got[0].append(backend.ChamferEMD(t[0], t[1], True, True))
+                    else:
+                        got[1].append((backend.MatchCostImplicit(t[2], t[3], True), ops.hip_knn(pts, 16)))
+            st.synchronize()
+        except Exception as e:  # surfaced below: an exception in a thread would otherwise vanish
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for r in got[0]:
+        assert all(torch.equal(x, y) for x, y in zip(r, want[0]))
+    for emd, knn in got[1]:
+        assert all(torch.equal(x, y) for x, y in zip(emd, want[1])) and torch.equal(knn, want[2])
+
+
 def test_package_import_before_torch(cuda):
     """The library must share torch's HIP runtime whatever the import order (``_lib`` imports torch before it loads
     the shared object): a fresh process that imports the package first, as ``__graft_entry__.build()`` followed by
