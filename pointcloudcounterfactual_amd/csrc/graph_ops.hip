@@ -152,7 +152,8 @@ __global__ __launch_bounds__(1024) void gather_lds_kernel(int c, int n, int k, c
     } else {
         const int out_c = MODE == 1 ? 2 * c : c;
         float *ob = out + (size_t)smp * out_c * nk;
-        if ((nk & 3) == 0 && k >= 4) {
+        // (16-byte accesses: whole float4 groups and 16-byte aligned bases -- a tensor view with a storage offset need not be)
+        if ((nk & 3) == 0 && k >= 4 && ((reinterpret_cast<uintptr_t>(ib) | reinterpret_cast<uintptr_t>(ob)) & 15) == 0) {
             // four consecutive edges per thread: the output is a write-only stream many times the L2 (838 MB at C=64,
             // k=25, B=32), stored as 16 bytes per lane; the index list as two 16-byte loads
             typedef float v4f __attribute__((ext_vector_type(4)));

@@ -102,6 +102,41 @@ def test_knn_sorted_search_random_sweep(cuda, oracle_mod):
         assert np.array_equal(idx[:, ::stride], exp[:, ::stride]), (trial, b, c, n, k, kind)
 
 
+def test_inputs_that_are_views_with_a_storage_offset(cuda):
+    """Contiguous tensors that start 4 bytes into their storage (slices of a larger buffer): every 16-byte fast path must
+    notice and every result must equal the one for an aligned copy."""
+    from pointcloudcounterfactual_amd import backend
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    def shifted(t):
+        buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.is_contiguous() and v.data_ptr() % 16 != 0
+        return v
+
+    g = torch.Generator().manual_seed(5)
+    x3 = torch.rand(3, 3, 1000, generator=g).to(cuda)
+    x64 = torch.randn(3, 64, 1000, generator=g).to(cuda)
+    a, c = torch.rand(3, 1000, 3, generator=g).to(cuda), torch.rand(3, 900, 3, generator=g).to(cuda)
+    idx = ops.hip_knn(x64, 20)
+    assert torch.equal(ops.hip_knn(shifted(x3), 20), ops.hip_knn(x3, 20))
+    assert torch.equal(ops.hip_knn(shifted(x64), 20), idx)
+    for fn in (lambda x, i: ops.get_graph_features(x, i, 20)[1], lambda x, i: ops.graph_max_pooling(x, i, 20),
+               lambda x, i: ops.get_neighbours(x, i, 20)[1]):
+        want = fn(x64, idx)
+        assert torch.equal(fn(shifted(x64), idx), want) and torch.equal(fn(x64, shifted(idx)), want)
+    want = ops.global_max_pool(x64)
+    got = ops.global_max_pool(shifted(x64))
+    assert all(torch.equal(p, q) for p, q in zip(got if isinstance(got, (tuple, list)) else [got],
+                                                 want if isinstance(want, (tuple, list)) else [want]))
+    for f in (lambda p, q: backend.NNDistance(p, q), lambda p, q: backend.MatchCostImplicit(p, q, True),
+              lambda p, q: backend.ChamferEMD(p, q, True, True)):
+        want = f(a, c)
+        got = f(shifted(a), shifted(c))
+        assert all(torch.equal(p, q) for p, q in zip(got, want))
+
+
 def test_knn_ties_ascending_index(cuda, oracle_mod):
     from pointcloudcounterfactual_amd import neighbour_ops as ops
 
