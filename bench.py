@@ -55,6 +55,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--reps', type=int, default=7,
+                    help='repetitions of the K timed steps; value = the median repetition, value_min/max beside it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the timings of the rows outside the headline metric')
     ap.add_argument('--cpu-clouds', type=int, default=0, help='clouds in the CPU-baseline sample (0 = auto)')
@@ -72,9 +74,10 @@ def parse() -> argparse.Namespace:
     return ap.parse_args()
 
 
-def self_launch(args: argparse.Namespace) -> int:
-    """Start the N ranks of this benchmark as a child ``torch.distributed.run`` (this process has not initialised HIP and
-    never does: it only relays the child's output and exit code)."""
+def self_launch(args: argparse.Namespace, script: str | None = None) -> int:
+    """Start the N ranks of this benchmark (or of ``script``: bench_train.py shares the launcher) as a child
+    ``torch.distributed.run`` (this process has not initialised HIP and never does: it only relays the child's output and
+    exit code)."""
     import socket
 
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -82,7 +85,7 @@ def self_launch(args: argparse.Namespace) -> int:
         port = s.getsockname()[1]
     argv = [a for a in sys.argv[1:] if a != '--via-launcher']
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(script or __file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     proc = subprocess.run(cmd, env=env)
     return proc.returncode
@@ -345,25 +348,65 @@ def cpu_baseline_and_parity(recon, ref, recon_t, ref_t, clouds: int) -> tuple[di
                   f'restated (torch expanded form + autograd, {t_threads} threads) {t_torch:.3f}s; approx-EMD fwd+bwd = oracle C '
                   f'restatement, OpenMP over the batch ({threads} threads) {t2 - t1:.3f}s; [oracle Chamfer fwd+bwd {t1 - t0:.3f}s]',
     }
+    # ---- parity of the node that is TIMED: backend.ChamferEMD (pcc_chamfer_emd: nn_sorted_kernel + the approximate-EMD
+    # chain + am_pair_kernel) and backend.ChamferEMDGrad (pcc_chamfer_emd_grad), i.e. exactly what chamfer_emd() calls
     with torch.no_grad():
         x1, x2 = recon_t[:clouds].contiguous(), ref_t[:clouds].contiguous()
-        h1, j1, h2, j2 = backend.NNDistance(x1, x2)
-        gg = torch.full((clouds, n), 1.0 / n, device=x1.device)
-        r1, r2 = backend.NNDistanceGrad(x1, x2, j1, j2, gg, gg)
-        cost, e1, e2 = backend.MatchCostImplicit(x1, x2, True)
+        lc, j1, j2, cost, e1, e2, h1, h2 = backend.ChamferEMD(x1, x2, True, True, return_dist=True)
+        ones = torch.ones((clouds,), device=x1.device)
+        zeros = torch.zeros((clouds,), device=x1.device)
+        # the two upstream scalars separately, so that each term of the one backward launch is checked on its own
+        r1, r2 = backend.ChamferEMDGrad(x1, x2, j1, j2, ones, True, e1, e2, zeros)
+        s1, s2 = backend.ChamferEMDGrad(x1, x2, j1, j2, zeros, True, e1, e2, ones)
+    # checker for the approximate EMD: the float64 recurrence, and the spread of the oracle's own legitimate float32
+    # evaluations around it (exp modes 0-3) -- the bars of test_parity_at_bench_point_size
+    om64, _ = oracle.approxmatch_f64(a, c)
+    oc64 = oracle.matchcost_f64(a, c, om64)
+    f64_1, f64_2 = oracle.matchcostgrad_f64(a, c, om64)
+    del om64
+    scale = float(max(np.abs(f64_1).max(), np.abs(f64_2).max()))
+    spread = float(max(np.abs(om1 - f64_1).max(), np.abs(om2 - f64_2).max()))
+    try:
+        for mode in (1, 2, 3):
+            oracle.set_exp_mode(mode)
+            mm, _ = oracle.approxmatch(a, c)
+            q1, q2 = oracle.matchcostgrad(a, c, mm)
+            del mm
+            spread = max(spread, float(np.abs(q1 - f64_1).max()), float(np.abs(q2 - f64_2).max()))
+    finally:
+        oracle.set_exp_mode(0)
     rel = lambda got, exp: float(np.abs(got - exp).max() / max(np.abs(exp).max(), 1e-30))  # noqa: E731
+    chamfer_loss_oracle = d1.astype(np.float64).mean(1) + d2.astype(np.float64).mean(1)
+    emd_grad_err = float(max(np.abs(s1.cpu().numpy() - f64_1).max(), np.abs(s2.cpu().numpy() - f64_2).max()))
+    emd_grad_bar = max(3.0 * spread, 1e-5 * scale)
     parity = {
-        'clouds': clouds, 'n_points': n, 'checker': 'oracle (float32 C restatement of the reference kernels) on the same bits',
+        'clouds': clouds, 'n_points': n,
+        'node': 'backend.ChamferEMD(return_dist=True) + backend.ChamferEMDGrad: the calls chamfer_emd() -- the timed step -- makes',
+        'checker': 'oracle on the same bits: float32 C restatement of nndistance.cu (indices, distances, Chamfer gradients); '
+                   'float64 recurrence of approxmatch.cu / matchcost (EMD cost and gradients)',
         'nn_idx_mismatches': int((j1.cpu().numpy() != i1).sum() + (j2.cpu().numpy() != i2).sum()),
-        'nn_dist_max_abs_err': float(max(np.abs(h1.cpu().numpy() - d1).max(), np.abs(h2.cpu().numpy() - d2).max())),
+        'nn_dist_bit_mismatches': int((h1.cpu().numpy().view(np.uint32) != d1.view(np.uint32)).sum()
+                                      + (h2.cpu().numpy().view(np.uint32) != d2.view(np.uint32)).sum()),
+        'chamfer_loss_max_rel_err': float(np.abs(lc.cpu().numpy() - chamfer_loss_oracle).max() / np.abs(chamfer_loss_oracle).max()),
         'chamfer_grad_max_err_rel_to_largest': max(rel(r1.cpu().numpy(), og1), rel(r2.cpu().numpy(), og2)),
         'chamfer_grad_vs_reference_torch_cpu_path_rel_to_largest': rel(r1.cpu().numpy(), ta.grad.numpy()),
-        'emd_cost_max_rel_err': float(np.abs(cost.cpu().numpy() - ocost).max() / np.abs(ocost).max()),
-        'emd_grad_max_err_rel_to_largest': max(rel(e1.cpu().numpy(), om1), rel(e2.cpu().numpy(), om2)),
-        'bars': 'indices / distances bit-exact; cost 1e-5; EMD gradients: the recurrence is ill-conditioned element-wise, '
-                'two legitimate float32 evaluations differ by 1e-4..9e-4 of the largest component at N=2048 '
-                '(tests/test_gpu_reference_pins.py::test_parity_at_bench_point_size)',
+        'emd_cost_max_rel_err_vs_f64': float((np.abs(cost.cpu().numpy() - oc64) / np.abs(oc64)).max()),
+        'emd_cost_max_rel_err_vs_f32_oracle': float((np.abs(cost.cpu().numpy() - ocost) / np.abs(ocost)).max()),
+        'emd_grad_max_abs_err_vs_f64': emd_grad_err,
+        'emd_grad_bar': emd_grad_bar,
+        'emd_grad_f32_oracle_spread_vs_f64': spread,
+        'emd_grad_largest_component': scale,
     }
+    parity['bars'] = {
+        'nn_idx_mismatches': 0, 'nn_dist_bit_mismatches': 0, 'chamfer_loss_max_rel_err': 1e-5,
+        'chamfer_grad_max_err_rel_to_largest': 1e-5, 'emd_cost_max_rel_err_vs_f64': 1e-5,
+        'emd_grad_max_abs_err_vs_f64': 'max(3 x spread of the four legitimate float32 evaluations of the oracle, 1e-5 of the '
+                                       'largest component) -- tests/test_gpu_reference_pins.py::test_parity_at_bench_point_size',
+    }
+    parity['bars_ok'] = bool(
+        parity['nn_idx_mismatches'] == 0 and parity['nn_dist_bit_mismatches'] == 0
+        and parity['chamfer_loss_max_rel_err'] <= 1e-5 and parity['chamfer_grad_max_err_rel_to_largest'] <= 1e-5
+        and parity['emd_cost_max_rel_err_vs_f64'] <= 1e-5 and emd_grad_err <= emd_grad_bar)
     return cpu, parity
 
 
@@ -411,16 +454,25 @@ def main() -> int:
 
     for _ in range(args.warmup):
         step(recon_t, ref_t)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(recon_t, ref_t)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # R repetitions of the K timed steps, each bracketed by barrier + synchronize on both sides and reduced with MAX
+    # over the ranks; `value` is the MEDIAN repetition (K=20 steps are a 10 ms window: one repetition is one sample
+    # of the clock, the spread is reported as value_min / value_max)
+    rep_s: list[float] = []
+    for _ in range(max(1, args.reps)):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(recon_t, ref_t)
+        sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        rep_s.append(el)
+    rep_sorted = sorted(rep_s)
+    elapsed = rep_sorted[len(rep_sorted) // 2] if len(rep_sorted) % 2 else 0.5 * (rep_sorted[len(rep_sorted) // 2 - 1]
+                                                                                 + rep_sorted[len(rep_sorted) // 2])
 
     clouds = B_PER_GPU * world * args.steps
     result = {
@@ -431,6 +483,10 @@ def main() -> int:
         'steps': args.steps,
         'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3,
+        'repetitions': len(rep_s),
+        'value_min': B_PER_GPU * world * args.steps / max(rep_s),
+        'value_max': B_PER_GPU * world * args.steps / min(rep_s),
+        'ms_per_step_all_repetitions': [r / args.steps * 1e3 for r in rep_s],
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,

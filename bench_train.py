@@ -4,10 +4,14 @@
   python bench_train.py --mode train --gpus N --steps K --warmup W   autoencoder training step, B=32 per GPU
   python bench_train.py --mode infer --gpus N ...                    classifier -> counterfactual (encoder, w-AE, codes, decoder) -> classifier + metric
 
-N>1: launch with ``python -m torch.distributed.run --nproc-per-node N ... bench_train.py --gpus N``; one rank per
-GPU, gradients averaged by DDP over RCCL (training) / no collective at all (inference).  Prints one JSON line on
-rank 0 in the bench.py format.  The headline metric of the repository stays bench.py; this file measures the rows
-SURVEY.md marks "next".
+One rank per GPU; gradients averaged by DDP over RCCL (training) / no collective at all (inference).  Under
+``torch.distributed.run`` (RANK / WORLD_SIZE in the environment) the process is one rank; without it ``--gpus N`` (N > 1,
+or ``--via-launcher`` at N = 1) starts its own N ranks as a CHILD of a parent that never touches the GPU -- bench.py's
+launcher (reference: ``src/utils/parallel.py:37-53`` spawns its ranks itself).  Whenever it runs under a launcher --
+also at world size 1 -- the process group is RCCL and the model is wrapped in DistributedDataParallel, so DDP's
+autograd-hook threads, the library's lane streams and its private memory pool execute together.  A line whose
+``n_gpus`` differs from ``--gpus`` is refused.  Prints one JSON line on rank 0 in the bench.py format.  The headline
+metric of the repository stays bench.py; this file measures the rows SURVEY.md marks "next".
 """
 
 from __future__ import annotations
@@ -22,10 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
 
-
-def main() -> None:
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument('--mode', choices=['train', 'infer'], default='train')
     ap.add_argument('--gpus', type=int, default=1)
@@ -37,14 +39,28 @@ def main() -> None:
     ap.add_argument('--graph', action='store_true',
                     help='capture one step into a hipGraph (torch.cuda.CUDAGraph) and replay it: the step is ~1500 launches, '
                          'a third of its wall time is launch gaps')
+    ap.add_argument('--via-launcher', action='store_true',
+                    help='start the ranks through torch.distributed.run even for --gpus 1 (RCCL + DDP at world size 1)')
     args = ap.parse_args()
+    launched = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if not launched and (args.gpus > 1 or args.via_launcher):
+        import bench
+
+        return bench.self_launch(args, script=__file__)
+
+    import torch
+
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for another job size')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench_train.py needs a GPU (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    if launched:  # one process per GPU over RCCL (backend "nccl" on ROCm), also at world size 1
         import torch.distributed as dist_mod
 
         dist = dist_mod
@@ -134,12 +150,15 @@ def main() -> None:
                        'parallelism': f'dp{world}' + (' (DDP all-reduce over RCCL)' if args.mode == 'train' else ' (no collective)')},
             'edgeconv': 'unfused (reference composition)' if args.unfused else 'fused (no [B,2C,N,k] tensor)',
             'hipgraph': bool(args.graph),
+            'launcher': 'torch.distributed.run + RCCL' + (' + DistributedDataParallel' if args.mode == 'train' else '')
+                        if launched else 'single process',
             'peak_mem_gib': torch.cuda.max_memory_allocated() / 2**30,
         }), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -34,10 +34,8 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
  * pcc_auction_backward on that device returns PCC_EINVAL with a message instead of starting, and
  * pcc_auction_status() returns 1 (each of them clears the word).  Launches are asynchronous: synchronise the stream
  * before asking.  Cluster launches issued on different streams are ordered one after the other by an event, so two of
- * them never compete for residency.  pcc_auction_test_inject_failure() makes the next cluster launch start with its
- * error word raised (test hook for the reporting path). */
+ * them never compete for residency.  (The reporting path is exercised through include/pcc_test_hooks.h.) */
 int pcc_auction_status(void);
-void pcc_auction_test_inject_failure(void);
 
 /* emd_cuda_backward (emd_cuda.cu:283-315): grad_xyz1[b,n,3] = 2 grad_dist (xyz1 - xyz2[assignment]); overwritten.
  * An assignment outside [0, n) contributes a zero gradient. */

@@ -70,8 +70,9 @@ ABI: dict[str, tuple[object, list[object]]] = {
     # include/pcc_emd.h
     'pcc_auction_forward': (_int, [_int, _int, _vp, _vp, ctypes.c_float, _int, _vp, _vp, _vp]),
     'pcc_auction_status': (_int, []),
-    'pcc_auction_test_inject_failure': (None, []),
     'pcc_auction_backward': (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    # include/pcc_test_hooks.h (inert without PCC_TEST_HOOKS=1)
+    'pcc_test_inject_auction_failure': (_int, []),
 }
 
 

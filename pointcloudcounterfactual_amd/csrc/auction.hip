@@ -8,9 +8,11 @@
 // Bid values follow emd_cuda.cu:145 literally: `3.0 - sqrtf(d2) - price` is DOUBLE arithmetic rounded once
 // to float; sqrtf is correctly rounded (-fno-fast-math).
 #include "pcc_common.hpp"
+#include <atomic>
 
 #include <mutex>
 #include "pcc_emd.h"
+#include "pcc_test_hooks.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -358,6 +360,21 @@ ClusterState *cluster_state() {
     }
     return &c;
 }
+// compute units of the CURRENT device (cached per device: a process may drive several)
+int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            v = 0;
+        }
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 // nonzero if an earlier cluster launch on this device timed out (and clears the word)
 int take_cluster_failure() {
     std::lock_guard<std::mutex> lk(g_cluster_mu);
@@ -388,11 +405,7 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
             const char *e = std::getenv("PCC_AUCTION_CLUSTER");
             return e ? std::atoi(e) : 0;
         }();
-        static const int cus = [] {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-            return v;
-        }();
+        const int cus = device_cus();
         int C = 1;
         if (cl_override != 1 && n >= 512 && cus > 0) {
             C = cl_override > 1 ? cl_override : 8;
@@ -477,9 +490,17 @@ int pcc_auction_status(void) {
     return take_cluster_failure() ? 1 : 0;
 }
 
-void pcc_auction_test_inject_failure(void) {
+// include/pcc_test_hooks.h -- NOT part of the product ABI: inert unless PCC_TEST_HOOKS=1 was in the environment when the
+// library first looked (the test-suite sets it; tests/conftest.py)
+int pcc_test_inject_auction_failure(void) {
+    static const bool armed = [] {
+        const char *e = std::getenv("PCC_TEST_HOOKS");
+        return e && e[0] == '1';
+    }();
+    if (!armed) return 0;
     std::lock_guard<std::mutex> lk(g_cluster_mu);
     if (ClusterState *cs = cluster_state()) cs->inject = true;
+    return 1;
 }
 
 int pcc_auction_backward(int b, int n, const float *xyz1, const float *xyz2, const float *grad_dist,

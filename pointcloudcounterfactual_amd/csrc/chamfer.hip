@@ -178,10 +178,39 @@ __global__ __launch_bounds__(64 * S) void nn_fwd_kernel(int b, int n, const floa
             // non-finite inputs as the reference treats them (nndistance.cu:26-28, `k == 0 || d < best`): candidate 0 is
             // always taken first, and nothing compares below NaN -- a NaN query point, or a NaN candidate 0, gives
             // dist = NaN with index 0; a NaN candidate elsewhere never wins.  The scan above ignores NaN (fminf, strict <).
-            const float d0 = sq3(C[0] - Q[q * 3 + 0], C[1] - Q[q * 3 + 1], C[2] - Q[q * 3 + 2]);
+            const float ux = Q[q * 3 + 0], uy = Q[q * 3 + 1], uz = Q[q * 3 + 2];
+            const float d0 = sq3(C[0] - ux, C[1] - uy, C[2] - uz);
             if (d0 != d0 || !(rb < __builtin_inff())) {
                 rb = d0;
                 ri = 0;
+            }
+            // The reference's `k == 0` is local to its 512-candidate chunks (nndistance.cu:4-10,26): a NaN distance to
+            // candidate 512*c (c >= 1) becomes that chunk's `best`, nothing in the chunk compares below it and the
+            // cross-chunk merge (`result > best`, :116) drops the chunk -- candidates 512c .. 512c+511 are hidden from
+            // this query.  Detected here with one distance per chunk head; such a query (a diverged input) is re-scanned
+            // by the reference's own rule, one candidate at a time.
+            bool quirk = false;
+            for (int h = 512; h < nc; h += 512) {
+                const float dh = sq3(C[h * 3 + 0] - ux, C[h * 3 + 1] - uy, C[h * 3 + 2] - uz);
+                quirk |= (dh != dh);
+            }
+            if (quirk && d0 == d0) {
+                for (int k2 = 0; k2 < nc; k2 += 512) {
+                    const int end_k = min(nc, k2 + 512);
+                    float best = 0.f;
+                    int best_i = 0;
+                    for (int k = k2; k < end_k; k++) {
+                        const float d = sq3(C[k * 3 + 0] - ux, C[k * 3 + 1] - uy, C[k * 3 + 2] - uz);
+                        if (k == k2 || d < best) {
+                            best = d;
+                            best_i = k;
+                        }
+                    }
+                    if (k2 == 0 || rb > best) {
+                        rb = best;
+                        ri = best_i;
+                    }
+                }
             }
             out_d[q] = rb;
             out_i[q] = ri;

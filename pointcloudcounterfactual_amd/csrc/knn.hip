@@ -191,7 +191,7 @@ struct KnnSortedArgs {
 
 // K = list slots (>= k), KPREV = the next smaller instantiation (k > KPREV)
 template <int K, int KPREV>
-__global__ __launch_bounds__(64 * kSW, (K <= 25 ? 4 : 1)) void knn_sorted_kernel(KnnSortedArgs a) {  // (<= 128 VGPRs up to K = 25: four waves per SIMD)
+__global__ __launch_bounds__(64 * kSW, (K == 16 ? 3 : K <= 25 ? 4 : 1)) void knn_sorted_kernel(KnnSortedArgs a) {  // (<= 128 VGPRs up to K = 25: four waves per SIMD; the carried chain of K = 16 needs 3 to stay out of scratch)
     // per wave: FIFO [kCap][64] x (distance, index), reused as the merge area [slice][K][16] x (distance 4 B | index 2 B:
     // n <= 16384) -- 6 bytes per entry keep K = 25 under 10 KB per wave, i.e. four waves per SIMD
     constexpr int kEntries = kSlices * K * kSQ;

@@ -34,6 +34,48 @@ def _prep(x: torch.Tensor, indices: torch.Tensor | None = None) -> None:
         raise RuntimeError('indices must be a contiguous int64 tensor [B,N,k] on the device of x')
 
 
+# ---- squared distances (reference neighbour_ops.py:16-50) -----------------------------------------------------------------
+
+
+def index_k_neighbours(pcs: list[Any], k: int) -> Any:
+    """Host-side kNN precompute of the dataset readers (reference ``neighbour_ops.py:16-24``; ``modelnet.py:18``):
+    a KD-tree per cloud, ``[len(pcs), N, k]``.  Dataset preparation, not on the device path."""
+    import numpy as np
+    from sklearn.neighbors import KDTree
+
+    indices_list = []
+    for pc in pcs:
+        indices = KDTree(pc).query(pc, k, return_distance=False)
+        indices_list.append(indices.reshape(-1, k))
+    return np.stack(indices_list)
+
+
+def pykeops_square_distance(t1: torch.Tensor, t2: torch.Tensor) -> Any:
+    """Lazy ``D[b,i,j] = |t1[b,i] - t2[b,j]|^2`` (reference ``neighbour_ops.py:35-40``) over this package's
+    ``LazyTensor`` (``keops_shim``): its reductions -- ``argmin`` / ``min`` over either axis, ``argKmin``, ``sum`` --
+    run the HIP kernels; the matrix never exists.  Imported by ``metrics_and_losses.py:18`` and ``quantize.py:6``."""
+    from pointcloudcounterfactual_amd.keops_shim import LazyTensor
+
+    t1_lazy = LazyTensor(t1[:, :, None, :])
+    t2_lazy = LazyTensor(t2[:, None, :, :])
+    return ((t1_lazy - t2_lazy) ** 2).sum(-1)
+
+
+def torch_square_distance(t1: torch.Tensor, t2: torch.Tensor) -> torch.Tensor:
+    """Dense expanded-form ``[B,N,M]`` squared distances (reference ``neighbour_ops.py:43-50``): the reference's CPU
+    path (``torch_chamfer``, ``metrics_and_losses.py:44-47``)."""
+    from pointcloudcounterfactual_amd.losses import torch_square_distance as impl
+
+    return impl(t1, t2)
+
+
+def square_distance(t1: torch.Tensor, t2: torch.Tensor) -> Any:
+    """Device dispatch of the reference (``neighbour_ops.py:27-32``): lazy on the accelerator, dense on the CPU."""
+    if t1.device.type == 'cuda':
+        return pykeops_square_distance(t1, t2)
+    return torch_square_distance(t1, t2)
+
+
 # ---- kNN ------------------------------------------------------------------------------------------------------
 
 
@@ -61,6 +103,12 @@ def hip_knn(x: torch.Tensor, k: int) -> torch.Tensor:
     with torch.cuda.device(x.device):
         _lib.check(_L.pcc_knn(b, c, n, k, x.data_ptr(), out.data_ptr(), _stream(x)), 'knn')
     return out
+
+
+def pykeops_knn(x: torch.Tensor, k: int) -> torch.Tensor:
+    """The reference's accelerator kNN (``neighbour_ops.py:77-82``: ``argKmin`` of the lazy self distance), here the
+    HIP search."""
+    return hip_knn(x.detach(), k)
 
 
 def knn(x: torch.Tensor, k: int) -> torch.Tensor:

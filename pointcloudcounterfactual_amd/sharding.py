@@ -84,3 +84,49 @@ def max_over_ranks(seconds: float, device: torch.device, group: dist.ProcessGrou
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def broadcast_(tensor: torch.Tensor, src: int = 0, group: dist.ProcessGroup | None = None) -> torch.Tensor:
+    """In-place broadcast of a replicated tensor from ``src`` (no-op without a process group)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.broadcast(tensor, src=src, group=group)
+    return tensor
+
+
+@torch.no_grad()
+def reseed_unused_codes_(codebook: torch.Tensor, usage_local: torch.Tensor, vq_noise: float, final_epoch: bool = False,
+                         generator: torch.Generator | None = None, group: dist.ProcessGroup | None = None) -> int:
+    """The reference's ``DiscreteSpaceOptimizer`` step (``src/train/hooks.py:47-77``) for a codebook replicated over
+    the ranks: entries of ``codebook[n_books, book_size, dim]`` that no sample selected are re-seeded from a used entry
+    of the same book, drawn with probability proportional to its usage, plus ``vq_noise`` Gaussian noise (``:74-77``);
+    in the final epoch they are parked at 1000 instead (``:70-72``).
+
+    Two deliberate differences from the reference, both on the multi-GPU side: the usage
+    counts ``usage_local[n_books, book_size]`` of every rank's shard are SUMMED first (the reference looks at rank 0's
+    shard only, ``:51-55``), and after rank 0 has rewritten the entries the codebook is BROADCAST -- the reference
+    mutates ``codebook.data`` on rank 0 alone (``:51``) and its replicas silently diverge.  Returns the number of
+    re-seeded entries (the same on every rank)."""
+    usage = usage_local.detach().to(torch.float64).clone()
+    distributed = dist.is_available() and dist.is_initialized()
+    if distributed:
+        dist.all_reduce(usage, op=dist.ReduceOp.SUM, group=group)
+    rank = dist.get_rank(group) if distributed else 0
+    unused = usage == 0
+    n_reseeded = int(unused.sum().item())
+    if rank == 0 and n_reseeded:
+        u_cpu = usage.cpu()
+        for book in range(codebook.shape[0]):
+            total = float(u_cpu[book].sum())
+            if total <= 0:  # nothing of this book was used: no template to draw from (the reference would divide by 0)
+                continue
+            probs = u_cpu[book] / total
+            for entry in torch.nonzero(unused[book].cpu()).flatten().tolist():
+                if final_epoch:
+                    codebook[book, entry] = 1000
+                    continue
+                sampled = int(torch.multinomial(probs, 1, generator=generator).item())
+                template = codebook[book, sampled]
+                noise = torch.randn(template.shape, generator=generator).to(template)
+                codebook[book, entry] = template + vq_noise * noise
+    broadcast_(codebook, 0, group)
+    return n_reseeded

@@ -8,6 +8,8 @@ import pytest
 # tail of the approximate EMD's dense candidate list was found: 0 * exp2(NaN coordinates) is NaN, not 0.)  Read once when
 # the library allocates its first workspace; child processes of the tests inherit it.
 os.environ.setdefault('PCC_WS_POISON', '1')
+# arms include/pcc_test_hooks.h (inert otherwise): the auction's failure-reporting path is driven through it
+os.environ.setdefault('PCC_TEST_HOOKS', '1')
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -80,6 +80,29 @@ def test_auction_gpu_matches_oracle(cuda, oracle_mod, b, n, eps, iters):
 
 
 @pytest.mark.gpu
+def test_auction_at_baseline_config2_workload(cuda, oracle_mod):
+    """BASELINE configs[2], auction reading, at its full workload: B=32, n=2048, eps=0.005, iters=50
+    (external/emd/README.md:7's training parameters), stress-set clouds (U[0,1]^3, seed 1234 + config id).
+    Forward (emd_cuda.cu:227-281): assignment and dist bit-exact against the deterministic oracle; backward
+    (emd_cuda.cu:283-315): grad_xyz1 = 2 g (p1 - p2[assignment]), grad_xyz2 = 0 (emd_module.py:76-79)."""
+    from emd import emdModule
+
+    a, c = pair(1234 + 2, 32, 2048, 2048, 'uniform')
+    t1 = torch.from_numpy(a).to(cuda).requires_grad_(True)
+    t2 = torch.from_numpy(c).to(cuda).requires_grad_(True)
+    dist, ass = emdModule()(t1, t2, 0.005, 50)
+    od, oa, _ = oracle_mod.auction_forward(a, c, 0.005, 50)
+    assert ass.dtype == torch.int32 and tuple(ass.shape) == (32, 2048)
+    assert np.array_equal(ass.cpu().numpy(), oa)
+    assert np.array_equal(dist.detach().cpu().numpy().view(np.uint32), od.view(np.uint32))
+    assert oa.min() >= 0 and oa.max() < 2048
+    g = torch.randn(32, 2048, generator=torch.Generator().manual_seed(3))
+    dist.backward(g.to(cuda))
+    np.testing.assert_allclose(t1.grad.cpu().numpy(), oracle_mod.auction_backward(a, c, g.numpy(), oa), rtol=1e-6, atol=1e-7)
+    assert t2.grad is None or float(t2.grad.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 def test_auction_many_samples_chunked_launches(cuda, oracle_mod):
     """More samples than one co-resident launch of 8-workgroup clusters holds (256 CUs / 8): consecutive launches."""
     from emd import emdModule
@@ -158,7 +181,7 @@ def test_auction_failure_is_reported_not_silent(cuda):
     t1, t2 = torch.from_numpy(a).to(cuda), torch.from_numpy(c).to(cuda)
     dist = torch.zeros(4, 2048, device=cuda)
     ass = torch.zeros(4, 2048, device=cuda, dtype=torch.int32)
-    _lib.lib.pcc_auction_test_inject_failure()
+    assert _lib.lib.pcc_test_inject_auction_failure() == 1  # armed: tests/conftest.py sets PCC_TEST_HOOKS=1
     assert emd_backend.forward(t1, t2, dist, ass, eps=0.005, iters=20) == 1  # the launch itself is asynchronous
     torch.cuda.synchronize()
     assert torch.isnan(dist).all() and (ass == -1).all()
@@ -174,7 +197,7 @@ def test_auction_failure_is_reported_not_silent(cuda):
     torch.cuda.synchronize()
     assert torch.isfinite(dist).all() and (ass >= 0).all()
     # and the other way round: a failed forward followed by a forward
-    _lib.lib.pcc_auction_test_inject_failure()
+    _lib.lib.pcc_test_inject_auction_failure()
     emd_backend.forward(t1, t2, dist, ass, eps=0.005, iters=20)
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match='did not complete'):

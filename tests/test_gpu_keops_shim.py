@@ -114,3 +114,23 @@ def test_general_dimension_argmin_and_sum_axes(cuda):
     np.testing.assert_allclose(dist.min(axis=2).squeeze(-1).cpu().numpy(), D.min(2)[0].cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(dist.sum(axis=2).squeeze(-1).cpu().numpy(), D.sum(2).cpu().numpy(), rtol=1e-5)
     np.testing.assert_allclose(dist.sum(axis=1).squeeze(-1).cpu().numpy(), D.sum(1).cpu().numpy(), rtol=1e-5)
+
+
+def test_neighbour_ops_square_distance_exports(cuda):
+    """``square_distance`` / ``pykeops_square_distance`` / ``pykeops_knn`` as the drop-in ``neighbour_ops`` exports them
+    (reference neighbour_ops.py:27-40,77-82; imported by metrics_and_losses.py:18 and quantize.py:6): the lazy distance's
+    reductions equal the dense float64 ones (indices exactly, away from ties; minima to 1e-6)."""
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    a, c = pair(611, 2, 300, 257)
+    t1, t2 = torch.from_numpy(a).to(cuda), torch.from_numpy(c).to(cuda)
+    dist = ops.square_distance(t1, t2)
+    assert type(dist) is type(ops.pykeops_square_distance(t1, t2)) and dist.shape == (2, 300, 257)
+    D = ((torch.from_numpy(a).double()[:, :, None, :] - torch.from_numpy(c).double()[:, None, :, :]) ** 2).sum(-1)
+    assert torch.equal(dist.argmin(axis=2).squeeze(-1).cpu(), D.argmin(2))
+    assert torch.equal(dist.argmin(axis=1).squeeze(-1).cpu(), D.argmin(1))
+    np.testing.assert_allclose(dist.min(axis=2).squeeze(-1).cpu().numpy(), D.min(2)[0].numpy(), rtol=1e-5, atol=1e-9)
+    x = t1.transpose(1, 2).contiguous()
+    assert torch.equal(ops.pykeops_knn(x, 5), ops.hip_knn(x, 5))
+    # the CPU side of the dispatch is the reference's dense expanded form
+    assert torch.allclose(ops.square_distance(t1.cpu(), t2.cpu()), D.float(), atol=1e-5)

@@ -742,3 +742,26 @@ def test_nndistance_non_finite_inputs_follow_the_reference(cuda, oracle_mod):
         assert np.array_equal(g[~np.isnan(exp)], exp[~np.isnan(exp)])
     assert np.array_equal(i1.cpu().numpy(), oi1) and np.array_equal(i2.cpu().numpy(), oi2)
     assert np.isnan(od1[0, 5]) and np.isnan(od1[1]).all() and not np.isnan(od1[0, :5]).any()
+
+
+def test_nndistance_nan_chunk_head_hides_its_chunk_like_the_reference(cuda, oracle_mod):
+    """The reference's `k == 0` (nndistance.cu:26) is local to its 512-candidate chunks: a NaN candidate at index 512*c
+    (c >= 1) becomes the chunk's `best`, nothing compares below NaN, and the cross-chunk merge (`result > best`, :116)
+    drops the whole chunk -- candidates 512c .. 512c+511 are hidden.  The oracle restates that loop; the HIP kernel must
+    give the same indices and distances (a NaN candidate at 513 is merely skipped; a NaN query gives NaN / index 0)."""
+    from pointcloudcounterfactual_amd import backend
+
+    a, c = pair(78, 2, 1500, 1300)
+    c[0, 512, 0] = np.nan       # hides candidates 512..1023 of sample 0 from every query of set 1
+    c[1, 1024, 2] = np.nan      # hides 1024..1299 of sample 1
+    c[1, 513, 1] = np.nan       # not a chunk head: skipped only
+    a[0, 1024] = np.nan         # the other direction: hides 1024..1499 of set 1 from the queries of set 2
+    d1, i1, d2, i2 = backend.NNDistance(_dev(a, cuda), _dev(c, cuda))
+    od1, oi1, od2, oi2 = oracle_mod.nndistance(a, c)
+    assert not ((oi1[0] >= 512) & (oi1[0] < 1024)).any() and not (oi1[1] >= 1024).any()  # the quirk is really there
+    assert not (oi2[0] >= 1024).any()
+    for got, exp in ((d1, od1), (d2, od2)):
+        g = got.cpu().numpy()
+        assert np.array_equal(np.isnan(g), np.isnan(exp))
+        assert np.array_equal(g[~np.isnan(exp)], exp[~np.isnan(exp)])
+    assert np.array_equal(i1.cpu().numpy(), oi1) and np.array_equal(i2.cpu().numpy(), oi2)
