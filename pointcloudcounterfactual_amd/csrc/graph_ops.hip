@@ -374,6 +374,250 @@ __global__ __launch_bounds__(1024) void nbrsum_bwd_sorted_kernel(int c, int n, i
     }
 }
 
+// ---- gather / edge-feature backward as a stream over the gradient ---------------------------------------------------------
+// grad_x[b,c,t] = sum over edges e = (i,j) with indices[b,i,j] == t of g[b,c,e]          (get_neighbours, neighbour_ops.py:85-94)
+//               + sum_j (g[b,C+c,t,j] - g[b,c,t,j])                                        (get_graph_features, :113-119)
+// The gradient is per EDGE: [B,(2)C,N,k] floats, 838 MB at B=32, C=64, N=2048, k=25 -- it has to be read once, coalesced,
+// and that read is the floor (~150 us).  scatter_lds_kernel does read it that way but pays one ds_add_f32 per edge
+// and channel (~3.5 cycles per LANE): 1.6 ms.  Here:
+//   * the edge list of a sample is cut into chunks of P source points (P*k <= kEsCE edges, what two channel rows of LDS
+//     hold) and every chunk is counting-sorted by TARGET once per call (edge_chunk_sort_kernel: LDS integer atomics; the
+//     graph is shared by all channels).  With every sorted entry goes a byte of flags: the segment structure of its
+//     64-entry group (which of the six steps of the wave-wide prefix sum add), whether the entry closes its target's segment inside the run
+//     of entries one wave walks, and whether that segment crosses a run boundary;
+//   * a workgroup owns CB channels of a sample: it stages the chunk's gradient rows in LDS with 16-byte streaming loads
+//     (the mandatory HBM traffic), its 8 waves each walk one contiguous run of the sorted entries -- LDS gather of
+//     g[c][e], segmented prefix sum over equal targets with the precomputed flags, an open segment carried from one
+//     64-entry group to the next in a register -- and only the entry that closes a segment touches the LDS bin: a plain
+//     read-modify-write (no two waves ever hold the same target, except the <= 7 segments that cross a run boundary:
+//     those use ds_add_f32);
+//   * the self terms of the edge features are k consecutive values per point: summed from the staged rows, one thread
+//     per (channel, point), plain adds.
+// Like scatter_add in torch (what the reference's gather backward runs) the order inside a target's segment comes from
+// integer atomics: the float summation order is not fixed.
+constexpr int kEsCE = 7680;     // edges per chunk (two channel rows of 30 KB + bins: two workgroups per CU at n <= 2560)
+constexpr int kEsWaves = 8;      // waves per workgroup of the stream kernel: two workgroups per CU run in different phases
+constexpr int kEsT = 64 * kEsWaves;
+constexpr int kEsMaxGroups = ((kEsCE + kEsWaves - 1) / kEsWaves + 63) / 64;  // 64-entry groups in the longest run of one wave
+
+__host__ __device__ inline int es_points_per_chunk(int n, int k) {
+    int p = (kEsCE / k) & ~63;  // whole waves of points (and P*k a multiple of 4: 16-byte loads stay aligned)
+    if (p < 64) return 0;
+    return p < n ? p : ((n + 63) & ~63);
+}
+__host__ __device__ inline int es_run_len(int cnt) {  // entries one wave walks: whole 64-entry groups
+    return ((cnt + kEsWaves - 1) / kEsWaves + 63) & ~63;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float es_dpp(float v) {  // the DPP-selected partner's value (0 where the lane has none)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+__device__ __forceinline__ float es_keep(float u, unsigned f, int bit) {  // u if bit `bit` of f is set, +0 otherwise
+    return __int_as_float(__float_as_int(u) & -(int)((f >> bit) & 1u));
+}
+
+__global__ __launch_bounds__(1024) void edge_chunk_sort_kernel(int n, int k, int P, const int64_t *__restrict__ indices,
+                                                                unsigned *__restrict__ ent, unsigned char *__restrict__ flg) {
+    extern __shared__ __attribute__((aligned(16))) int es_lds[];  // start[n] | cur[n] | key[kEsCE]
+    int *start = es_lds, *cur = es_lds + n;
+    unsigned *key = reinterpret_cast<unsigned *>(es_lds + 2 * (size_t)n);
+    __shared__ int wave_tot[16];
+    const int ch = blockIdx.x, smp = blockIdx.y, tid = threadIdx.x, T = 1024, lane = tid & 63, w = tid >> 6;
+    const int i0 = ch * P, pc = min(P, n - i0), cnt = pc * k;
+    const size_t nk = (size_t)n * k;
+    const int64_t *ib = indices + (size_t)smp * nk + (size_t)i0 * k;
+    unsigned *E = ent + (size_t)smp * nk + (size_t)i0 * k;
+    unsigned char *F = flg + (size_t)smp * nk + (size_t)i0 * k;
+    for (int i = tid; i < n; i += T) cur[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < cnt; e += T) atomicAdd(&cur[nbr(ib[e], n, i0 + e / k)], 1);
+    __syncthreads();
+    // exclusive scan of the n counts: every thread owns a contiguous run
+    const int per = (n + T - 1) / T;
+    const int beg = min(tid * per, n), end = min(beg + per, n);
+    int mine = 0;
+    for (int i = beg; i < end; i++) mine += cur[i];
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        incl += lane >= off ? v : 0;
+    }
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int i = 0; i < w; i++) before += wave_tot[i];
+    int run = before + incl - mine;
+    for (int i = beg; i < end; i++) {
+        const int c = cur[i];
+        cur[i] = run;
+        start[i] = run;
+        run += c;
+    }
+    __syncthreads();
+    for (int e = tid; e < cnt; e += T) {
+        const int t = nbr(ib[e], n, i0 + e / k);
+        key[atomicAdd(&cur[t], 1)] = ((unsigned)t << 13) | (unsigned)e;  // e < kEsCE <= 8192
+    }
+    __syncthreads();
+    const int L = es_run_len(cnt);
+    for (int p = tid; p < cnt; p += T) {
+        const unsigned kp = key[p];
+        const int t = (int)(kp >> 13), ln = p & 63;
+        // steps of the wave-wide segmented prefix sum of edge_stream_bwd_kernel (DPP: no LDS round trips): four shifts
+        // inside the 16-lane row, then lane 15 / 47 into the next row, then lane 31 into the upper half
+        unsigned f = 0;
+        const int lr = ln & 15;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++)
+            if (lr >= (1 << s4) && (int)(key[p - (1 << s4)] >> 13) == t) f |= 1u << s4;
+        if ((ln & 16) && (int)(key[p - lr - 1] >> 13) == t) f |= 16u;
+        if (ln >= 32 && (int)(key[p - ln + 31] >> 13) == t) f |= 32u;
+        const int seg_first = start[t], seg_last = cur[t] - 1;  // (cur[t] has advanced to the end of the segment)
+        const bool seg_end = p == seg_last, run_end = ((p + 1) % L == 0) || p == cnt - 1;
+        if (seg_end || run_end) f |= 64u;                       // flush the running sum into the bin here
+        if (seg_first / L != seg_last / L) f |= 128u;            // the segment is shared by two waves: atomic flush
+        E[p] = kp;
+        F[p] = (unsigned char)f;
+    }
+}
+
+// MODE 0: gather backward; MODE 1: edge-feature backward (g has 2C rows: the second half only feeds the self terms)
+template <int MODE, int CB>
+__global__ __launch_bounds__(kEsT) void edge_stream_bwd_kernel(int c, int n, int k, int P, const unsigned *__restrict__ ent,
+                                                                const unsigned char *__restrict__ flg,
+                                                                const float *__restrict__ g, float *__restrict__ grad_x) {
+    extern __shared__ __attribute__((aligned(16))) float es_f[];  // buf[CB][kEsCE] | bins[CB][n]
+    float *buf = es_f, *bins = es_f + (size_t)CB * kEsCE;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int nblk = (c + CB - 1) / CB, lid = pcc::xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int smp = lid / nblk, c0 = (lid - smp * nblk) * CB;
+    const int tid = threadIdx.x, T = kEsT, lane = tid & 63, w = tid >> 6;
+    const size_t nk = (size_t)n * k;
+    const int gc = MODE == 1 ? 2 * c : c;
+    const unsigned *Eb = ent + (size_t)smp * nk;
+    const unsigned char *Fb = flg + (size_t)smp * nk;
+    for (int i = tid; i < CB * n; i += T) bins[i] = 0.f;
+    auto stage = [&](int row0, size_t e0, int cnt) {  // buf[cc][0 .. cnt) = g[b, row0 + cc, e0 ...]
+#pragma unroll
+        for (int cc = 0; cc < CB; cc++) {
+            if (c0 + cc >= c) continue;
+            const float *src = g + ((size_t)smp * gc + row0 + cc) * nk + e0;
+            float *dst = buf + (size_t)cc * kEsCE;
+            if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+                const int c4 = cnt & ~3;
+                for (int i = tid * 4; i < c4; i += T * 4)
+                    *reinterpret_cast<v4f *>(dst + i) = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + i));
+                for (int i = c4 + tid; i < cnt; i += T) dst[i] = src[i];
+            } else {
+                for (int i = tid; i < cnt; i += T) dst[i] = src[i];
+            }
+        }
+    };
+    for (int i0 = 0; i0 < n; i0 += P) {
+        const int pc = min(P, n - i0), cnt = pc * k;
+        const size_t e0 = (size_t)i0 * k;
+        // this wave's run of the chunk's sorted entries: independent of the gradient rows, so the loads go out first
+        const int L = es_run_len(cnt), run0 = w * L, p_end = min((w + 1) * L, cnt);
+        unsigned kp_r[kEsMaxGroups], f_r[kEsMaxGroups];
+#pragma unroll
+        for (int gi = 0; gi < kEsMaxGroups; gi++) {
+            const int p = run0 + gi * 64 + lane;
+            const bool valid = p < p_end;
+            kp_r[gi] = valid ? Eb[e0 + p] : 0xffffffffu;
+            f_r[gi] = valid ? (unsigned)Fb[e0 + p] : 0u;
+        }
+        __syncthreads();  // bins zeroed / the previous chunk's buffer fully consumed
+        stage(c0, e0, cnt);
+        __syncthreads();
+        // ---- scattered terms: this wave's run of the chunk's target-sorted entries (fetched above, before the staging
+        // barrier: inside the loop each group's entry load would be a dependent L2 round trip, ~1.5 us x 7 groups) ----
+        {
+            float carry[CB];
+            int carry_t = -1;
+#pragma unroll
+            for (int cc = 0; cc < CB; cc++) carry[cc] = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < kEsMaxGroups; gi++) {
+                const int p0 = run0 + gi * 64;
+                if (p0 < p_end) {  // (wave-uniform)
+                    const bool valid = p0 + lane < p_end;
+                    const unsigned kp = kp_r[gi], f = f_r[gi];
+                    const int t = valid ? (int)(kp >> 13) : -2;
+                    const int el = (int)(kp & 8191u) % kEsCE;  // (an invalid lane reads a harmless in-range address)
+                    float v[CB];
+#pragma unroll
+                    for (int cc = 0; cc < CB; cc++) v[cc] = valid ? buf[(size_t)cc * kEsCE + el] : 0.f;
+#pragma unroll
+                    for (int cc = 0; cc < CB; cc++) {
+                        // segmented inclusive prefix sum over the 64 lanes with cross-lane VALU operands (row_shr 1 2 4 8,
+                        // row_bcast 15 into rows 1 and 3, row_bcast 31 into rows 2 and 3); a lane adds at a step iff its flag
+                        // says the partner belongs to the same target
+                        // (the partner's value is taken by ALL lanes and then masked with bit arithmetic: written as a
+                        // select, the compiler moves the DPP move under the flag's exec mask, and a lane whose own flag is
+                        // clear then is an inactive -- invalid -- source for its neighbour)
+                        float x = v[cc];
+                        x += es_keep(es_dpp<0x111, 0xf>(x), f, 0);
+                        x += es_keep(es_dpp<0x112, 0xf>(x), f, 1);
+                        x += es_keep(es_dpp<0x114, 0xf>(x), f, 2);
+                        x += es_keep(es_dpp<0x118, 0xf>(x), f, 3);
+                        x += es_keep(es_dpp<0x142, 0xa>(x), f, 4);
+                        x += es_keep(es_dpp<0x143, 0xc>(x), f, 5);
+                        v[cc] = x;
+                    }
+                    // the segment left open by the previous group of this run continues at the head of this one
+                    const bool head = t == carry_t;
+                    const int t63 = __builtin_amdgcn_readlane(t, 63);              // (wave-uniform: scalar registers)
+                    const unsigned f63 = (unsigned)__builtin_amdgcn_readlane((int)f, 63);
+#pragma unroll
+                    for (int cc = 0; cc < CB; cc++) {
+                        v[cc] += head ? carry[cc] : 0.f;
+                        carry[cc] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[cc]), 63));
+                    }
+                    carry_t = (f63 & 64u) ? -1 : t63;  // flushed at lane 63 (or past the end): nothing to carry
+                    if (valid && (f & 64u)) {
+                        if (f & 128u) {
+#pragma unroll
+                            for (int cc = 0; cc < CB; cc++) atomicAdd(&bins[(size_t)cc * n + t], v[cc]);
+                        } else {
+#pragma unroll
+                            for (int cc = 0; cc < CB; cc++) bins[(size_t)cc * n + t] += v[cc];
+                        }
+                    }
+                }
+            }
+        }
+        if (MODE == 1) {
+            __syncthreads();
+            // self terms, first half: bin i loses sum_j g[c][i,j] (one thread per (channel, point): plain updates)
+            for (int q = tid; q < CB * pc; q += T) {
+                const int cc = q / pc, il = q - cc * pc;
+                const float *row = buf + (size_t)cc * kEsCE + (size_t)il * k;
+                float sum = 0.f;
+                for (int j = 0; j < k; j++) sum += row[j];
+                bins[(size_t)cc * n + i0 + il] -= sum;
+            }
+            __syncthreads();
+            stage(c + c0, e0, cnt);
+            __syncthreads();
+            for (int q = tid; q < CB * pc; q += T) {
+                const int cc = q / pc, il = q - cc * pc;
+                const float *row = buf + (size_t)cc * kEsCE + (size_t)il * k;
+                float sum = 0.f;
+                for (int j = 0; j < k; j++) sum += row[j];
+                bins[(size_t)cc * n + i0 + il] += sum;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < CB * n; i += T) {
+        const int cc = i / n, t = i - cc * n;
+        if (c0 + cc < c) grad_x[((size_t)smp * c + c0 + cc) * n + t] = bins[i];
+    }
+}
+
 // One wave per (b,c) row: max (first maximum), argmax and mean over n.  HBM-bound (the encoder's [B,1024,N] tensor is
 // 256 MiB at B=32, N=2048): rows are streamed with 16-byte non-temporal loads, eight in flight per lane before the first
 // use; a lane's indices only grow, so inside a lane the strict compare already keeps the first maximum and the index
@@ -483,9 +727,72 @@ int gather_fwd(int b, int c, int n, int k, const float *x, const int64_t *indice
     return pcc::check_launch(what);
 }
 
+// gather / edge-feature backward as a stream over the gradient (edge_chunk_sort_kernel + edge_stream_bwd_kernel);
+// returns -1 when the sizes do not qualify (the caller then runs the per-edge scatter)
+template <int MODE>
+int edge_stream_bwd(int b, int c, int n, int k, const int64_t *indices, const float *g, float *grad_x, hipStream_t st) {
+    static const bool enabled = [] {  // PCC_EDGE_SCATTER=1: the per-edge atomic scatter (A/B measurements)
+        const char *e = std::getenv("PCC_EDGE_SCATTER");
+        return !(e && e[0] == '1');
+    }();
+    const int P = es_points_per_chunk(n, k);
+    if (!enabled || P == 0 || n > 32768) return -1;
+    int cb = 2;
+    auto lds_of = [&](int v) { return (size_t)v * kEsCE * sizeof(float) + (size_t)v * n * sizeof(float); };
+    if (lds_of(cb) > 80 * 1024) cb = 1;
+    const size_t lds = lds_of(cb), lds_sort = ((size_t)2 * n + kEsCE) * sizeof(int);
+    if (lds > 160 * 1024 - 256 || lds_sort > 160 * 1024 - 256) return -1;
+    const size_t nk = (size_t)n * k;
+    char *ws = nullptr;
+    const size_t ent_bytes = ((size_t)b * nk * sizeof(unsigned) + 15) & ~(size_t)15;
+    if (pcc::ws_malloc(reinterpret_cast<void **>(&ws), ent_bytes + (size_t)b * nk, st) != hipSuccess) {
+        (void)hipGetLastError();
+        pcc::set_error(PCC_ENOMEM, "graph op backward: workspace allocation failed");
+        return PCC_ENOMEM;
+    }
+    unsigned *ent = reinterpret_cast<unsigned *>(ws);
+    unsigned char *flg = reinterpret_cast<unsigned char *>(ws + ent_bytes);
+    static bool attr_sort = [] {
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(edge_chunk_sort_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        return ok;
+    }();
+    (void)attr_sort;
+    {
+        pcc::ProfScope prof("edge_chunk_sort_kernel", st);
+        hipLaunchKernelGGL(edge_chunk_sort_kernel, dim3((unsigned)pcc::ceil_div(n, P), (unsigned)b), dim3(1024), lds_sort, st, n, k, P,
+                           indices, ent, flg);
+    }
+    const dim3 grid((unsigned)(pcc::ceil_div(c, cb) * b));
+    {
+        pcc::ProfScope prof(MODE == 1 ? "edge_stream_bwd_kernel<features>" : "edge_stream_bwd_kernel<gather>", st);
+#define PCC_LAUNCH_E(CB)                                                                                                  \
+    do {                                                                                                                  \
+        static bool attr = [] {                                                                                           \
+            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(edge_stream_bwd_kernel<MODE, CB>),         \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess; \
+            if (!ok) (void)hipGetLastError();                                                                             \
+            return ok;                                                                                                    \
+        }();                                                                                                              \
+        (void)attr;                                                                                                       \
+        hipLaunchKernelGGL((edge_stream_bwd_kernel<MODE, CB>), grid, dim3(kEsT), lds, st, c, n, k, P, ent, flg, g, grad_x); \
+    } while (0)
+        if (cb == 2) PCC_LAUNCH_E(2);
+        else PCC_LAUNCH_E(1);
+#undef PCC_LAUNCH_E
+    }
+    (void)pcc::ws_free(ws, st);
+    return pcc::check_launch("graph op backward (edge stream)");
+}
+
 template <int MODE>
 int scatter_bwd(int b, int c, int n, int k, const int64_t *indices, const int32_t *argmax, const float *g,
                 float *grad_x, hipStream_t st, const char *what) {
+    if (MODE == 0 || MODE == 1) {
+        const int rc = edge_stream_bwd<(MODE == 1 ? 1 : 0)>(b, c, n, k, indices, g, grad_x, st);
+        if (rc >= 0) return rc;
+    }
     // channels per workgroup: as many as fit 64 KiB of bins (two workgroups per CU)
     int cb = 8;
     while (cb > 1 && (size_t)cb * n * sizeof(float) > 64 * 1024) cb >>= 1;

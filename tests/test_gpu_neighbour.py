@@ -199,6 +199,44 @@ def test_graph_ops_forward_backward(cuda, b, c, n, k):
         torch.testing.assert_close(tg.grad.cpu(), tr.grad, rtol=1e-5, atol=1e-5, msg=name)
 
 
+@pytest.mark.parametrize('b,c,n,k,kind', [(2, 64, 2048, 25, 'knn'), (2, 5, 700, 7, 'random'), (1, 3, 300, 4, 'hub'),
+                                            (2, 9, 1000, 20, 'invalid'), (1, 2, 64, 100, 'random'), (1, 3, 5000, 3, 'random')])
+def test_gather_and_feature_backward_edge_stream(cuda, b, c, n, k, kind):
+    """Backward of get_neighbours / get_graph_features (neighbour_ops.py:85-119: torch.gather's scatter_add) on the
+    streaming kernels (edge_chunk_sort_kernel + edge_stream_bwd_kernel): several chunks of source points, ragged last
+    chunk, arbitrary (non-kNN) graphs, a hub every point links to (segments that span many waves' runs), neighbour
+    indices outside [0, n) (replaced by the point itself, as in the forward), k large enough for one-wave chunks --
+    against float64 scatter_add."""
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    g = torch.Generator().manual_seed(n + k)
+    x = torch.randn(b, c, n, generator=g)
+    if kind == 'knn':
+        idx = ops.knn(x.to(cuda), k).cpu()
+    else:
+        idx = torch.randint(0, n, (b, n, k), generator=g)
+        if kind == 'hub':
+            idx[:, :, 0] = 7
+            idx[:, : n // 2, 1:] = 3
+        if kind == 'invalid':
+            idx[:, ::5, 2] = n + 3
+            idx[:, 1::7, 0] = -1
+    self_idx = torch.arange(n).view(1, n, 1).expand(b, n, k)
+    eff = torch.where((idx >= 0) & (idx < n), idx, self_idx)  # what the kernels do with an index outside the cloud
+    for name, width in (('gather', c), ('features', 2 * c)):
+        w = torch.randn(b, width, n, k, generator=g)
+        tg = x.to(cuda).requires_grad_(True)
+        out = (ops.get_neighbours(tg, idx.to(cuda), k)[1] if name == 'gather' else ops.get_graph_features(tg, idx.to(cuda), k)[1])
+        out.backward(w.to(cuda))
+        wd = w.double()
+        ref = torch.zeros(b, c, n, dtype=torch.float64)
+        ref.scatter_add_(2, eff.reshape(b, 1, n * k).expand(b, c, n * k), wd[:, :c].reshape(b, c, n * k))
+        if name == 'features':
+            ref += (wd[:, c:] - wd[:, :c]).sum(3)
+        scale = ref.abs().max().item()
+        assert (tg.grad.cpu().double() - ref).abs().max().item() <= 2e-6 * scale + 1e-6, (name, kind)
+
+
 def test_graph_ops_vs_reference_fixture(cuda):
     from pointcloudcounterfactual_amd import neighbour_ops as ops
 
