@@ -290,6 +290,20 @@ def other_rows_us(dev) -> dict[str, float]:
     idx = ops.hip_knn(x, 25)
     out['graph_features_c64_k25_fwd'] = ev(lambda: ops.get_graph_features(x, idx, 25))
     out['graph_max_pooling_c64_k25_fwd'] = ev(lambda: ops.graph_max_pooling(x, idx, 25))
+    # backward of the two gathers on a gradient tensor already resident in HBM (the C call alone: autograd's
+    # `.sum().backward()` would first materialise its expanded scalar -- an 838 MB copy that is not this kernel's)
+    from pointcloudcounterfactual_amd import _lib
+
+    L, st = _lib.lib, torch.cuda.current_stream().cuda_stream
+    gx = torch.empty(B_PER_GPU, 64, N_POINTS, device=dev)
+    g2 = torch.randn(B_PER_GPU, 128, N_POINTS, 25, device=dev)
+    out['graph_features_c64_k25_bwd'] = ev(lambda: L.pcc_graph_features_bwd(B_PER_GPU, 64, N_POINTS, 25, idx.data_ptr(), g2.data_ptr(),
+                                                                           gx.data_ptr(), st))
+    g1 = g2[:, :64].contiguous()
+    del g2
+    out['get_neighbours_c64_k25_bwd'] = ev(lambda: L.pcc_gather_neighbours_bwd(B_PER_GPU, 64, N_POINTS, 25, idx.data_ptr(), g1.data_ptr(),
+                                                                            gx.data_ptr(), st))
+    del g1
     x2 = torch.randn(B_PER_GPU, 1024, N_POINTS, generator=g).to(dev)
     out['global_max_pool_c1024'] = ev(lambda: ops.global_max_pool(x2))
     out['global_max_pool_c1024_torch'] = ev(lambda: x2.max(dim=2))

@@ -6,6 +6,10 @@
   profiles/pmc_summary.json         HBM bytes per launch for the dominant kernels, corrected as
                                     MI355X_MICROARCH.md prescribes (FETCH_SIZE is in KiB and under-reports
                                     wide coalesced reads by 2x on gfx950; WRITE_SIZE is exact)
+
+  summarise_profiles.py <tag> [<out_tag> [nosummary]]: the secondary runs of tools/profile_bench.sh (<tag>x = the bench
+  with its extra rows: k-NN, graph ops, pooling, auction; <tag>n = the PCC_AM_NOCULL=1 probe) are written with
+  `nosummary`, which leaves pmc_summary.json -- the headline run's -- alone.
 """
 import csv
 import glob
@@ -18,6 +22,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 out_tag = sys.argv[2] if len(sys.argv) > 2 else tag
+write_summary = not (len(sys.argv) > 3 and sys.argv[3] == 'nosummary')  # secondary runs keep pmc_summary.json (the headline's)
 G = os.path.join(ROOT, 'gpurun_out')
 P = os.path.join(ROOT, 'profiles')
 os.makedirs(P, exist_ok=True)
@@ -25,7 +30,7 @@ os.makedirs(P, exist_ok=True)
 
 def short(name: str) -> str:
     name = name.replace('(anonymous namespace)::', '').replace('void ', '', 1) if name.startswith('void ') else name.replace('(anonymous namespace)::', '')
-    m = re.search(r'(am_\w+|nn_\w+|pair_\w+|chamfer_\w+|reduce_\w+|knn_\w+|gather_\w+|scatter_\w+|global_\w+|graph_\w+|auction_\w+|emd_\w+)(<[^>(]*>)?', name)
+    m = re.search(r'(am_\w+|nn_\w+|pair_\w+|chamfer_\w+|reduce_\w+|knn_\w+|gather_\w+|scatter_\w+|edge_\w+|sqnorm_\w+|global_\w+|graph_\w+|auction_\w+|emd_\w+|bn_\w+|nbrsum_\w+)(<[^>(]*>)?', name)
     if m:
         return m.group(0)
     return re.sub(r'\(.*', '', name)[:80] or 'unnamed'
@@ -97,5 +102,6 @@ if pmc:
         # narrow accesses); WRITE_SIZE is exact.  Units are KiB.
         v['hbm_bytes_per_launch'] = (2.0 * v['fetch_kib_raw'] + v['write_kib']) * 1024.0
         v['source'] = f'profiles/{out_tag}_pmc.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes)'
-    json.dump(summary, open(os.path.join(P, 'pmc_summary.json'), 'w'), indent=1)
-    print('wrote profiles/pmc_summary.json')
+    if write_summary:
+        json.dump(summary, open(os.path.join(P, 'pmc_summary.json'), 'w'), indent=1)
+        print('wrote profiles/pmc_summary.json')
