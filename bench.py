@@ -199,12 +199,14 @@ def phase_kernel_time_us(recon_t, ref_t, steps: int) -> tuple[float, int, int]:
 
 
 def phase_probe(args: argparse.Namespace) -> int:
-    """Child process of the no-skip measurement: the switches of the library are read once per process, so the
-    run with PCC_AM_NOCULL=1 (every exact-zero skip off: the kernels execute the reference's full arithmetic) lives in
-    its own process and reports through one JSON line."""
+    """Child process of the no-skip measurement: every exact-zero skip off (measurement switch `am_nocull` of
+    include/pcc_test_hooks.h, armed by PCC_TEST_HOOKS=1 in this child's environment: the kernels execute the
+    reference's full arithmetic); its own process, one JSON line."""
     import torch
 
-    from pointcloudcounterfactual_amd import backend
+    from pointcloudcounterfactual_amd import _lib, backend
+
+    _lib.set_tuning('am_nocull', 1)
 
     dev = torch.device('cuda', 0)
     _, _, recon_t, ref_t = make_inputs(0, dev, args.kind)
@@ -225,10 +227,10 @@ def phase_probe(args: argparse.Namespace) -> int:
 
 
 def noskip_roofline(steps: int) -> dict:
-    """am_phase_kernel with every exact-zero skip switched off (PCC_AM_NOCULL=1, child process): the kernels then
+    """am_phase_kernel with every exact-zero skip switched off (child process with the `am_nocull` switch): the kernels then
     execute exactly the reference's arithmetic, algorithmic == executed, and algorithmic flops / time / peak is a true
     fraction of the vector rate."""
-    env = dict(os.environ, PCC_AM_NOCULL='1')
+    env = dict(os.environ, PCC_TEST_HOOKS='1')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), '--phase-probe', '--steps', str(steps)], env=env,
@@ -242,7 +244,7 @@ def noskip_roofline(steps: int) -> dict:
     achieved = p['lanes'] * flop_per_launch / (p['phase_us'] * 1e-6) / 1e12
     return {'avg_launch_us': p['phase_us'], 'concurrent_launches': p['lanes'], 'achieved': achieved, 'peak': PEAK_F32_TFLOPS,
             'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_TFLOPS, 'emd_fwd_bwd_us': p['emd_fwd_bwd_us'],
-            'note': 'PCC_AM_NOCULL=1: no term is skipped, the kernels execute the 27 reference passes in full '
+            'note': 'measurement switch am_nocull: no term is skipped, the kernels execute the 27 reference passes in full '
                     '(13 flop-equivalents per pair per pass), so this fraction is algorithmic AND executed'}
 
 

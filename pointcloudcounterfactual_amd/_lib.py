@@ -73,6 +73,7 @@ ABI: dict[str, tuple[object, list[object]]] = {
     'pcc_auction_backward': (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp]),
     # include/pcc_test_hooks.h (inert without PCC_TEST_HOOKS=1)
     'pcc_test_inject_auction_failure': (_int, []),
+    'pcc_test_set_tuning': (_int, [_int, _int]),
 }
 
 
@@ -98,3 +99,14 @@ def check(status: int, what: str) -> None:
     if status != 0:
         msg = lib.pcc_last_error().decode() or f'HIP kernel failed : {status}'
         raise RuntimeError(f'{what}: {msg}')
+
+
+# include/pcc_test_hooks.h: measurement / bit-identity switches (inert unless PCC_TEST_HOOKS=1 is in the environment)
+TUNING = {'pair_plain_order': 1, 'am_nocull': 2, 'am_nosplit': 3, 'am_noresident': 4, 'edge_scatter': 5,
+          'nbrsum_scatter': 6, 'auction_cluster': 7}
+
+
+def set_tuning(name: str, value: int) -> None:
+    """Set a measurement switch of the library (0 = the product's behaviour); raises if the hooks are not armed."""
+    if lib.pcc_test_set_tuning(TUNING[name], int(value)) != 1:
+        raise RuntimeError('test hooks are not armed: set PCC_TEST_HOOKS=1 before the library is loaded')

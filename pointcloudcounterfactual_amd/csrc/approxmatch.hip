@@ -35,6 +35,7 @@
 // transcendental bound; matchcost and the fused gradient kernel of the materialising path are HBM bound
 // (one read of match each).
 #include "pcc_common.hpp"
+#include "pcc_test_hooks.h"
 
 #include <algorithm>
 #include <functional>
@@ -318,13 +319,15 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             total += c;
         }
         int pos = before + incl - mine;
+        // an exhausted owner keeps remainR = 0 (and ratioR = 0 from the zero-filled level array): the zero is carried
+        // over into the output buffer by the LIVE tiles of the sample, dealt round-robin (tile 0 alone -- the first
+        // workgroup of every launch -- used to write all of them: up to 2000 stores on the launch's critical path)
+        const int live_tiles = max(1, (total + TQ - 1) / TQ);
         auto place = [&](int i, bool flag) {
             if (flag) {
                 if (pos >= lo && pos < hi) own_idx[pos - lo] = i;
                 pos++;
-            } else if (tile == 0 && i < a.n_own) {
-                // an exhausted owner keeps remainR = 0 (and ratioR = 0 from the zero-filled level array); the
-                // first workgroup of the sample carries the zero over into the output buffer
+            } else if (i < a.n_own && (i % live_tiles) == tile) {
                 a.remain_out[(size_t)smp * a.remain_stride + i] = 0.f;
             }
         };
@@ -1993,6 +1996,8 @@ struct PairArgs {
     float *cost_part;           // [b][gridDim.y * gridDim.x]
     float *part1;               // [b][row_tiles][n4][3]   column sums (grad1, sorted space)
     float *part2;               // [b][col_blocks][m4][3]  row sums    (grad2, sorted space)
+    int col_blocks, row_tiles, bc;  // 1-D grid of col_blocks * row_tiles * bc workgroups (see the kernel)
+    int plain_order;
 };
 
 template <int Q, bool GRAD>
@@ -2003,9 +2008,21 @@ __global__ __launch_bounds__(256) void am_pair_kernel(PairArgs a) {
     __shared__ float lds_red[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int smp = blockIdx.z;
-    const int l0 = blockIdx.y * kPairRT;
-    const int kb = blockIdx.x * 64 * Q;
+    // Dispatch order = work order.  A workgroup's duration goes from ~0 (every row of the tile masked out for this column
+    // box) to the full 128 x 256 pairs on all live levels, and the heavy ones are the (row tile, column block) pairs that
+    // are CLOSE in space -- close along the two Hilbert orders.  In (x, y, z) grid order the last workgroups dispatched
+    // were as likely heavy as light and the chip idled 22 % of the kernel behind them (SQ_BUSY_CU_CYCLES).  The 1-D grid
+    // is read shift-major instead: for every shift 0, +1, -1, +2, ... of the row tile against the column block's own
+    // position along the curve, every column block, every sample -- near pairs first, far (short) ones last.
+    const int cbn = a.col_blocks, rtn = a.row_tiles;
+    const int item = (int)blockIdx.x / a.bc, smp = (int)blockIdx.x - item * a.bc;
+    const int shift_k = item / cbn, cblk = item - shift_k * cbn;
+    const int base_r = (int)(((long long)(2 * cblk + 1) * rtn) / (2 * cbn));
+    const int shift = ((shift_k + 1) >> 1) * ((shift_k & 1) ? 1 : -1);  // 0, +1, -1, +2, ... : a complete residue system mod rtn
+    int rtile = ((base_r + shift) % rtn + rtn) % rtn;
+    if (a.plain_order) rtile = shift_k;  // (A/B switch 1: row tiles in index order)
+    const int l0 = rtile * kPairRT;
+    const int kb = cblk * 64 * Q;
     const int k0 = kb + lane * Q;
     const size_t nm4 = (size_t)a.n4 + a.m4;
     const float *lvb = a.lv + (size_t)smp * kLevels * nm4;
@@ -2147,7 +2164,7 @@ __global__ __launch_bounds__(256) void am_pair_kernel(PairArgs a) {
             const int sl = v / 3, c = v - sl * 3;
             const int li = base + 4 * sl + w;
             if (lane < 24 && li < lcnt)
-                a.part2[(((size_t)smp * gridDim.x + blockIdx.x) * a.m4 + (l0 + li)) * 3 + c] = t + hi;
+                a.part2[(((size_t)smp * cbn + cblk) * a.m4 + (l0 + li)) * 3 + c] = t + hi;
         }
     }
     // cost partial of this workgroup
@@ -2156,7 +2173,7 @@ __global__ __launch_bounds__(256) void am_pair_kernel(PairArgs a) {
     if (lane == 0) lds_red[w] = csum;
     __syncthreads();
     if (tid == 0)
-        a.cost_part[(size_t)smp * gridDim.x * gridDim.y + blockIdx.y * gridDim.x + blockIdx.x] =
+        a.cost_part[(size_t)smp * cbn * rtn + rtile * cbn + cblk] =
             ((lds_red[0] + lds_red[1]) + lds_red[2]) + lds_red[3];
     if (GRAD) {
         // column sums: waves 1..3 hand theirs to wave 0 one after the other (fixed order); the stash is free now
@@ -2178,7 +2195,7 @@ __global__ __launch_bounds__(256) void am_pair_kernel(PairArgs a) {
             }
         }
         if (w == 0) {
-            float *dst = a.part1 + (((size_t)smp * gridDim.y + blockIdx.y) * a.n4) * 3;
+            float *dst = a.part1 + (((size_t)smp * rtn + rtile) * a.n4) * 3;
 #pragma unroll
             for (int q = 0; q < Q; q++) {
                 if (k0 + q < a.n) {
@@ -2262,12 +2279,8 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
 // ---- host side -------------------------------------------------------------------------------------
 constexpr int kPhCH = 2048;
 
-static bool cull_enabled() {  // PCC_AM_NOCULL=1 disables every work-skipping variant (A/B measurements)
-    static const bool v = [] {
-        const char *e = std::getenv("PCC_AM_NOCULL");
-        return !(e && e[0] == '1');
-    }();
-    return v;
+static bool cull_enabled() {  // measurement switch (pcc_test_hooks.h): every work-skipping variant off
+    return pcc::tuning(PCC_TUNE_AM_NOCULL) == 0;
 }
 
 template <int MODE>
@@ -2531,12 +2544,8 @@ unsigned take_resident_failure() {
     if (!r || !r->host_word) return 0;
     return __atomic_exchange_n(r->host_word, 0u, __ATOMIC_RELAXED);
 }
-static bool resident_enabled() {  // PCC_AM_NORESIDENT=1: one launch per pass at the fine levels too (A/B measurements, bit-identity test)
-    static const bool v = [] {
-        const char *e = std::getenv("PCC_AM_NORESIDENT");
-        return !(e && e[0] == '1');
-    }();
-    return v;
+static bool resident_enabled() {  // measurement switch (pcc_test_hooks.h): one launch per pass at the fine levels too
+    return pcc::tuning(PCC_TUNE_AM_NORESIDENT) == 0;
 }
 // the seven fine-level passes of the samples of `sc` as one resident launch; returns -1 when the device / the sizes do
 // not qualify (the caller then runs one launch per pass)
@@ -2600,10 +2609,7 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         return (e && e[0] == '1') ? 1 : 0;
     }();
 
-    static const bool split_enabled = [] {  // PCC_AM_NOSPLIT=1: everything on the caller's stream (A/B measurements)
-        const char *e = std::getenv("PCC_AM_NOSPLIT");
-        return !(e && e[0] == '1');
-    }();
+    const bool split_enabled = pcc::tuning(PCC_TUNE_AM_NOSPLIT) == 0;  // (measurement switch: everything on the caller's stream)
 
     // Lanes: disjoint sample ranges that run the same schedule on different streams.  Two lanes when each half still
     // is a sizeable launch (B=32, N=2048: EMD forward+backward 530 -> 49x us); every workspace section is indexed
@@ -2803,7 +2809,10 @@ int match_cost_implicit_impl(int b, int n, int m, const float *xyz1, const float
         pa.cost_part = reinterpret_cast<float *>(base + cpart_off) + o * col_blocks * row_tiles;
         pa.part1 = grad ? reinterpret_cast<float *>(base + part1_off) + o * row_tiles * L.n4 * 3 : nullptr;
         pa.part2 = grad ? reinterpret_cast<float *>(base + part2_off) + o * col_blocks * L.m4 * 3 : nullptr;
-        const dim3 grid(col_blocks, row_tiles, bc);
+        pa.col_blocks = col_blocks; pa.row_tiles = row_tiles; pa.bc = bc;
+        pa.plain_order = pcc::tuning(PCC_TUNE_PAIR_PLAIN_ORDER);
+        if ((long long)col_blocks * row_tiles * bc > 0x7fffffffLL) return pcc::invalid("match_cost: grid too large");
+        const dim3 grid((unsigned)(col_blocks * row_tiles * bc));
         if (int rc = launch_pair<q_cols>(pa, grid, grad, lst)) return rc;
         FinishArgs f{};
         f.parts[0] = row_tiles; f.parts[1] = col_blocks; f.parts[2] = col_blocks * row_tiles;

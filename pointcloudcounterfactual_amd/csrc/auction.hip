@@ -401,10 +401,8 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     // ---- cluster schedule: C workgroups per sample when they can all be resident at once ----
     {
-        static const int cl_override = [] {  // PCC_AUCTION_CLUSTER=1 forces one workgroup per sample, 2..16 forces C
-            const char *e = std::getenv("PCC_AUCTION_CLUSTER");
-            return e ? std::atoi(e) : 0;
-        }();
+        // measurement switch (pcc_test_hooks.h): 1 forces one workgroup per sample, 2..16 forces C
+        const int cl_override = pcc::tuning(PCC_TUNE_AUCTION_CLUSTER);
         const int cus = device_cus();
         int C = 1;
         if (cl_override != 1 && n >= 512 && cus > 0) {

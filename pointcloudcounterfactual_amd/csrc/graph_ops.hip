@@ -9,6 +9,7 @@
 
 #include <cstdlib>
 #include "pcc_neighbour.h"
+#include "pcc_test_hooks.h"
 
 namespace {
 
@@ -731,10 +732,7 @@ int gather_fwd(int b, int c, int n, int k, const float *x, const int64_t *indice
 // returns -1 when the sizes do not qualify (the caller then runs the per-edge scatter)
 template <int MODE>
 int edge_stream_bwd(int b, int c, int n, int k, const int64_t *indices, const float *g, float *grad_x, hipStream_t st) {
-    static const bool enabled = [] {  // PCC_EDGE_SCATTER=1: the per-edge atomic scatter (A/B measurements)
-        const char *e = std::getenv("PCC_EDGE_SCATTER");
-        return !(e && e[0] == '1');
-    }();
+    const bool enabled = pcc::tuning(PCC_TUNE_EDGE_SCATTER) == 0;  // (measurement switch: the per-edge atomic scatter)
     const int P = es_points_per_chunk(n, k);
     if (!enabled || P == 0 || n > 32768) return -1;
     int cb = 2;
@@ -895,10 +893,7 @@ int pcc_neighbour_sum_bwd(int b, int c, int n, int k, const int64_t *indices, co
     if (b == 0 || n == 0) return PCC_OK;
     if (!indices || !grad_out || !grad_x) return pcc::invalid("neighbour_sum_bwd: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const bool sorted_enabled = [] {  // PCC_NBRSUM_SCATTER=1: the per-edge atomic scatter (A/B measurements)
-        const char *e = std::getenv("PCC_NBRSUM_SCATTER");
-        return !(e && e[0] == '1');
-    }();
+    const bool sorted_enabled = pcc::tuning(PCC_TUNE_NBRSUM_SCATTER) == 0;  // (measurement switch: the per-edge atomic scatter)
     // sorted-edge schedule: needs 16-bit point ids and rows + bins of >= 1 channel in LDS
     if (sorted_enabled && n <= 65536 && (size_t)n * 8 <= 128 * 1024 && (size_t)n * 4 <= 160 * 1024 - 256) {
         unsigned *rev = nullptr;

@@ -10,7 +10,12 @@ thread_local int t_status = 0;
 thread_local char t_msg[320] = "";
 }  // namespace
 
+namespace {
+int g_tuning[16] = {};
+}
+
 namespace pcc {
+int tuning(int key) { return key >= 0 && key < 16 ? __atomic_load_n(&g_tuning[key], __ATOMIC_RELAXED) : 0; }
 void set_error(int status, const char *what) {
     t_status = status;
     std::strncpy(t_msg, what ? what : "", sizeof t_msg - 1);
@@ -138,4 +143,16 @@ int pcc_profile_read(const char *kernel_prefix, double *avg_us, int *launches) {
 const char *pcc_version(void) { return "pcc_structural 0.1 (gfx950)"; }
 const char *pcc_last_error(void) { return t_msg; }
 int pcc_last_status(void) { return t_status; }
+}
+
+#include <cstdlib>
+#include "pcc_test_hooks.h"
+extern "C" int pcc_test_set_tuning(int key, int value) {
+    static const bool armed = [] {
+        const char *e = std::getenv("PCC_TEST_HOOKS");
+        return e && e[0] == '1';
+    }();
+    if (!armed || key < 0 || key >= 16) return 0;
+    __atomic_store_n(&g_tuning[key], value, __ATOMIC_RELAXED);
+    return 1;
 }

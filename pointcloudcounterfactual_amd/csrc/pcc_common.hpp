@@ -38,6 +38,10 @@ __device__ __forceinline__ float sq3(float x, float y, float z) {
     return __builtin_fmaf(z, z, __builtin_fmaf(x, x, y * y));
 }
 
+// A/B switches for measurements inside ONE process (include/pcc_test_hooks.h: pcc_test_set_tuning; inert without
+// PCC_TEST_HOOKS=1): the value of switch `key` (0 = the product's behaviour).
+int tuning(int key);
+
 // Optional hipEvent bracket around one kernel launch (pcc_profile_* in the C ABI).
 bool profiling();
 struct ProfScope {

@@ -114,33 +114,22 @@ def test_auction_many_samples_chunked_launches(cuda, oracle_mod):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('cluster', ['1', '4', '16'])
+@pytest.mark.parametrize('cluster', [1, 4, 16])
 def test_auction_cluster_sizes_agree(cuda, oracle_mod, cluster):
-    """One workgroup per sample (PCC_AUCTION_CLUSTER=1, the schedule for batches that fill the chip on their own) and
-    other cluster sizes give the oracle's bits too (the variable is read once per process: child process)."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
+    """One workgroup per sample (the schedule for batches that fill the chip on their own) and other cluster sizes
+    (measurement switch `auction_cluster`, include/pcc_test_hooks.h) give the oracle's bits too."""
+    from emd import emdModule
+    from pointcloudcounterfactual_amd import _lib
 
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "from emd import emdModule\n"
-        "z = np.load(sys.argv[1])\n"
-        "d, a = emdModule()(torch.from_numpy(z['a']).cuda(), torch.from_numpy(z['c']).cuda(), 0.005, 30)\n"
-        "np.savez(sys.argv[2], d=d.cpu().numpy(), a=a.cpu().numpy())\n"
-    ) % root
     a, c = _clouds(5, 3, 2048)
     od, oa, _ = oracle_mod.auction_forward(a, c, 0.005, 30)
-    with tempfile.TemporaryDirectory() as d:
-        fin, fout = os.path.join(d, 'in.npz'), os.path.join(d, 'out.npz')
-        np.savez(fin, a=a, c=c)
-        r = subprocess.run([sys.executable, '-c', code, fin, fout], env=dict(os.environ, PCC_AUCTION_CLUSTER=cluster),
-                           capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        out = np.load(fout)
-        assert np.array_equal(out['a'], oa) and np.array_equal(out['d'], od)
+    _lib.set_tuning('auction_cluster', cluster)
+    try:
+        d, asg = emdModule()(torch.from_numpy(a).to(cuda), torch.from_numpy(c).to(cuda), 0.005, 30)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_tuning('auction_cluster', 0)
+    assert np.array_equal(asg.cpu().numpy(), oa) and np.array_equal(d.cpu().numpy(), od)
 
 
 @pytest.mark.gpu

@@ -407,14 +407,9 @@ def test_chamfer_fused_equals_nn_distance_expression(cuda, b, n, m, reduction):
 
 def test_two_lane_schedule_equals_single_stream(cuda):
     """At the bench size (B=32, N=2048) the level passes run as two half-batch lanes on two streams.
-    Per sample nothing changes, so the results carry the same bits as the single-stream schedule
-    (PCC_AM_NOSPLIT=1, read once per process: child process), run to run."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-
-    from pointcloudcounterfactual_amd import backend
+    Per sample nothing changes, so the results carry the same bits as the single-stream schedule (measurement switch
+    `am_nosplit`, include/pcc_test_hooks.h), run to run."""
+    from pointcloudcounterfactual_amd import _lib, backend
 
     a, c = pair(91, 32, 2048, 2048)
     t1, t2 = _dev(a, cuda), _dev(c, cuda)
@@ -422,74 +417,51 @@ def test_two_lane_schedule_equals_single_stream(cuda):
     r2 = backend.MatchCostImplicit(t1, t2, True)
     assert all(torch.equal(x, y) for x, y in zip(r1, r2))
     m1 = backend.ApproxMatchCost(t1, t2)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "from tests.util import pair; from pointcloudcounterfactual_amd import backend\n"
-        "a, c = pair(91, 32, 2048, 2048)\n"
-        "t1, t2 = torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda()\n"
-        "cost, g1, g2 = backend.MatchCostImplicit(t1, t2, True)\n"
-        "m, t, mc = backend.ApproxMatchCost(t1, t2)\n"
-        "np.savez(sys.argv[1], cost=cost.cpu().numpy(), g1=g1.cpu().numpy(), g2=g2.cpu().numpy(), mc=mc.cpu().numpy(),\n"
-        "         temp=t.cpu().numpy(), rowmass=m.sum(2).cpu().numpy())\n"
-    ) % root
-    with tempfile.TemporaryDirectory() as d:
-        f = os.path.join(d, 'single.npz')
-        r = subprocess.run([sys.executable, '-c', code, f], env=dict(os.environ, PCC_AM_NOSPLIT='1'),
-                           capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        z = np.load(f)
-    assert np.array_equal(r1[0].cpu().numpy(), z['cost'])
-    assert np.array_equal(r1[1].cpu().numpy(), z['g1']) and np.array_equal(r1[2].cpu().numpy(), z['g2'])
-    assert np.array_equal(m1[2].cpu().numpy(), z['mc']) and np.array_equal(m1[1].cpu().numpy(), z['temp'])
-    assert np.array_equal(m1[0].sum(2).cpu().numpy(), z['rowmass'])
+    rowmass1 = m1[0].sum(2)
+    temp1, mc1 = m1[1].clone(), m1[2].clone()
+    del m1
+    _lib.set_tuning('am_nosplit', 1)
+    try:
+        s1 = backend.MatchCostImplicit(t1, t2, True)
+        sm = backend.ApproxMatchCost(t1, t2)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_tuning('am_nosplit', 0)
+    assert all(torch.equal(x, y) for x, y in zip(r1, s1))
+    assert torch.equal(mc1, sm[2]) and torch.equal(temp1, sm[1]) and torch.equal(rowmass1, sm[0].sum(2))
 
 
 def test_resident_fine_levels_equal_one_launch_per_pass(cuda):
     """Levels 0-2 (passes A0 B0 CA0 B1 CA1 B2 CA2) run as ONE resident launch with per-sample barriers
     (am_fine_persist_kernel) when both clouds fit its LDS (<= 2048 points) and the whole launch fits the device
-    (batch x tiles <= compute units: b <= 8 at N = 2048); PCC_AM_NORESIDENT=1 (read once per process: child process) runs
-    them as one launch per pass (am_fine_kernel).  Same walk, same reduction order: every output
-    carries the same bits -- cost, both gradients, the materialised path's cost, temp (remainL | remainR | ratioL |
-    ratioR of the last level) and the row masses of match -- at the bench batch, at unequal clouds, at ragged sizes and
-    at clouds smaller than one tile."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-
-    from pointcloudcounterfactual_amd import backend
+    (batch x tiles <= compute units: b <= 8 at N = 2048); the measurement switch `am_noresident` runs them as one
+    launch per pass (am_fine_kernel).  Same walk, same reduction order: every output carries the same bits -- cost,
+    both gradients, the materialised path's cost, temp (remainL | remainR | ratioL | ratioR of the last level) and the
+    row masses of match -- at the largest qualifying batch, at unequal clouds, at ragged sizes and at clouds smaller
+    than one tile."""
+    from pointcloudcounterfactual_amd import _lib, backend
 
     shapes = [(8, 2048, 2048, 'recon'), (3, 1000, 2048, 'recon'), (2, 2048, 700, 'uniform'), (5, 257, 130, 'recon'),
               (2, 40, 17, 'uniform'), (9, 1024, 1024, 'uniform'), (1, 1, 1, 'recon')]
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
-        "from tests.util import pair; from pointcloudcounterfactual_amd import backend\n"
-        "out = {}\n"
-        "for k, (b, n, m, kind) in enumerate(%r):\n"
-        "    a, c = pair(300 + k, b, n, m, kind)\n"
-        "    t1, t2 = torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda()\n"
-        "    cost, g1, g2 = backend.MatchCostImplicit(t1, t2, True)\n"
-        "    mt, t, mc = backend.ApproxMatchCost(t1, t2)\n"
-        "    out.update({f'cost{k}': cost.cpu().numpy(), f'g1{k}': g1.cpu().numpy(), f'g2{k}': g2.cpu().numpy(),\n"
-        "                f'mc{k}': mc.cpu().numpy(), f'temp{k}': t.cpu().numpy(), f'rowmass{k}': mt.sum(2).cpu().numpy()})\n"
-        "np.savez(sys.argv[1], **out)\n"
-    ) % (root, shapes)
-    with tempfile.TemporaryDirectory() as d:
-        f = os.path.join(d, 'perpass.npz')
-        r = subprocess.run([sys.executable, '-c', code, f], env=dict(os.environ, PCC_AM_NORESIDENT='1'),
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        z = dict(np.load(f))
-    for k, (b, n, m, kind) in enumerate(shapes):
+
+    def run(k, b, n, m, kind):
         a, c = pair(300 + k, b, n, m, kind)
         t1, t2 = _dev(a, cuda), _dev(c, cuda)
         cost, g1, g2 = backend.MatchCostImplicit(t1, t2, True)
         mt, t, mc = backend.ApproxMatchCost(t1, t2)
-        for name, got in (('cost', cost), ('g1', g1), ('g2', g2), ('mc', mc), ('temp', t), ('rowmass', mt.sum(2))):
-            assert np.array_equal(got.cpu().numpy(), z[f'{name}{k}'], equal_nan=True), (name, b, n, m, kind)
-        assert torch.isfinite(cost).all()
+        return {'cost': cost, 'g1': g1, 'g2': g2, 'mc': mc, 'temp': t, 'rowmass': mt.sum(2)}
+
+    for k, shape in enumerate(shapes):
+        resident = run(k, *shape)
+        _lib.set_tuning('am_noresident', 1)
+        try:
+            per_pass = run(k, *shape)
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_tuning('am_noresident', 0)
+        for name in resident:
+            assert np.array_equal(resident[name].cpu().numpy(), per_pass[name].cpu().numpy(), equal_nan=True), (name, shape)
+        assert torch.isfinite(resident['cost']).all()
 
 
 def test_stale_workspace_does_not_leak_into_results(cuda):

@@ -11,6 +11,10 @@ a, c = pair(1236, B, N, N, 'recon')
 t1, t2 = torch.from_numpy(a).to(dev), torch.from_numpy(c).to(dev)
 cost = torch.empty(B, device=dev); g1 = torch.empty(B, N, 3, device=dev); g2 = torch.empty(B, N, 3, device=dev)
 st = torch.cuda.current_stream().cuda_stream
+if os.environ.get('PCC_AM_NOSPLIT') == '1':  # tool-side switch -> the library's measurement hook (it reads no behaviour variables)
+    os.environ['PCC_TEST_HOOKS'] = '1'
+    from pointcloudcounterfactual_amd import _lib as _l
+    _l.set_tuning('am_nosplit', 1)
 tag = ' '.join(f'{k}={v}' for k, v in sorted(os.environ.items()) if k.startswith('PCC_')) or 'default'
 def call():
     L.pcc_match_cost(B, N, N, t1.data_ptr(), t2.data_ptr(), None, cost.data_ptr(), g1.data_ptr(), g2.data_ptr(), st)

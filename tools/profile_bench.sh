@@ -20,9 +20,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}x_stats -- py
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}x_pmc_fetch -- python3 $R/bench.py $XARGS > $OUT/${TAG}x_pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}x_pmc_write -- python3 $R/bench.py $XARGS > $OUT/${TAG}x_pmc_write.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/${TAG}x_pmc_sq -- python3 $R/bench.py $XARGS > $OUT/${TAG}x_pmc_sq.log 2>&1 || echo "no SQ pass for the extras"
-# ---- the no-skip probe (every exact-zero skip off: algorithmic == executed work): the variable is inherited by the program ----
-export PCC_AM_NOCULL=1
+# ---- the no-skip probe (bench.py --phase-probe sets the am_nocull switch of pcc_test_hooks.h: every exact-zero skip off,
+# algorithmic == executed work); the arming variable is inherited by the program ----
+export PCC_TEST_HOOKS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}n_stats -- python3 $R/bench.py --phase-probe --steps 10 > $OUT/${TAG}n_stats.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $OUT/${TAG}n_pmc_sq -- python3 $R/bench.py --phase-probe --steps 10 > $OUT/${TAG}n_pmc_sq.log 2>&1 || echo "no SQ pass for the probe"
-unset PCC_AM_NOCULL
+unset PCC_TEST_HOOKS
 echo profiled

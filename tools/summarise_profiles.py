@@ -8,7 +8,7 @@
                                     wide coalesced reads by 2x on gfx950; WRITE_SIZE is exact)
 
   summarise_profiles.py <tag> [<out_tag> [nosummary]]: the secondary runs of tools/profile_bench.sh (<tag>x = the bench
-  with its extra rows: k-NN, graph ops, pooling, auction; <tag>n = the PCC_AM_NOCULL=1 probe) are written with
+  with its extra rows: k-NN, graph ops, pooling, auction; <tag>n = the no-skip probe) are written with
   `nosummary`, which leaves pmc_summary.json -- the headline run's -- alone.
 """
 import csv

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.util import pair
 from pointcloudcounterfactual_amd import _lib, backend
 L = _lib.lib
+if os.environ.get('PCC_AM_NORESIDENT') == '1':  # (tool-side switch; the library itself reads no behaviour variables)
+    os.environ['PCC_TEST_HOOKS'] = '1'; _lib.set_tuning('am_noresident', 1)
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 a, c = pair(1236, B, 2048, 2048)
