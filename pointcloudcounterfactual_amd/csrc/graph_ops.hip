@@ -387,17 +387,18 @@ __global__ __launch_bounds__(1024) void nbrsum_bwd_sorted_kernel(int c, int n, i
 //     64-entry group (which of the six steps of the wave-wide prefix sum add), whether the entry closes its target's segment inside the run
 //     of entries one wave walks, and whether that segment crosses a run boundary;
 //   * a workgroup owns CB channels of a sample: it stages the chunk's gradient rows in LDS with 16-byte streaming loads
-//     (the mandatory HBM traffic), its 8 waves each walk one contiguous run of the sorted entries -- LDS gather of
+//     (the mandatory HBM traffic), its 16 waves each walk one contiguous run of the sorted entries -- LDS gather of
 //     g[c][e], segmented prefix sum over equal targets with the precomputed flags, an open segment carried from one
 //     64-entry group to the next in a register -- and only the entry that closes a segment touches the LDS bin: a plain
-//     read-modify-write (no two waves ever hold the same target, except the <= 7 segments that cross a run boundary:
+//     read-modify-write (no two waves ever hold the same target, except the <= 15 segments that cross a run boundary:
 //     those use ds_add_f32);
-//   * the self terms of the edge features are k consecutive values per point: summed from the staged rows, one thread
-//     per (channel, point), plain adds.
+//   * the self terms of the edge features are k consecutive values per point: the second half of the gradient only feeds
+//     them and is reduced by its own streaming kernel (edge_self_sum_kernel); the first half's are summed from the staged
+//     rows, one thread per (channel, point), plain updates.
 // Like scatter_add in torch (what the reference's gather backward runs) the order inside a target's segment comes from
 // integer atomics: the float summation order is not fixed.
 constexpr int kEsCE = 7680;     // edges per chunk (two channel rows of 30 KB + bins: two workgroups per CU at n <= 2560)
-constexpr int kEsWaves = 8;      // waves per workgroup of the stream kernel: two workgroups per CU run in different phases
+constexpr int kEsWaves = 16;     // waves per workgroup of the stream kernel (<= 64 VGPRs: two workgroups, 8 waves per SIMD, per CU)
 constexpr int kEsT = 64 * kEsWaves;
 constexpr int kEsMaxGroups = ((kEsCE + kEsWaves - 1) / kEsWaves + 63) / 64;  // 64-entry groups in the longest run of one wave
 
@@ -485,9 +486,42 @@ __global__ __launch_bounds__(1024) void edge_chunk_sort_kernel(int n, int k, int
     }
 }
 
-// MODE 0: gather backward; MODE 1: edge-feature backward (g has 2C rows: the second half only feeds the self terms)
+// The self term of the SECOND half of the edge-feature gradient: grad_x[b,c,i] = sum_j g[b, C + c, i, j] -- k consecutive
+// values per point, a pure streaming reduction (419 MB at B=32, C=64, N=2048, k=25).  Written first; the stream kernel
+// below adds the scattered terms and the first half's self term on top.  A workgroup takes 256 points of one (b, c) row:
+// coalesced 16-byte loads into LDS, then one thread per point.
+constexpr int kSelfPts = 256;
+__global__ __launch_bounds__(256) void edge_self_sum_kernel(int c, int n, int k, const float *__restrict__ g, float *__restrict__ grad_x) {
+    extern __shared__ __attribute__((aligned(16))) float ss_buf[];  // [kSelfPts * k]
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int tiles = (n + kSelfPts - 1) / kSelfPts;
+    const int row = (int)(blockIdx.x / (unsigned)tiles);  // b * c + channel
+    const int smp = row / c, ch = row - smp * c;
+    const int i0 = (int)(blockIdx.x - (unsigned)row * tiles) * kSelfPts, pc = min(kSelfPts, n - i0), cnt = pc * k;
+    const size_t nk = (size_t)n * k;
+    const float *src = g + ((size_t)smp * 2 * c + c + ch) * nk + (size_t)i0 * k;
+    const int tid = threadIdx.x;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const int c4 = cnt & ~3;
+        for (int i = tid * 4; i < c4; i += 256 * 4)
+            *reinterpret_cast<v4f *>(ss_buf + i) = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + i));
+        for (int i = c4 + tid; i < cnt; i += 256) ss_buf[i] = src[i];
+    } else {
+        for (int i = tid; i < cnt; i += 256) ss_buf[i] = src[i];
+    }
+    __syncthreads();
+    if (tid < pc) {
+        const float *r = ss_buf + (size_t)tid * k;
+        float sum = 0.f;
+        for (int j = 0; j < k; j++) sum += r[j];
+        grad_x[(size_t)row * n + i0 + tid] = sum;
+    }
+}
+
+// MODE 0: gather backward (grad_x written); MODE 1: edge-feature backward, first half of g (the scattered terms minus the
+// self term sum_j g[c][i,j]), ADDED to what edge_self_sum_kernel has written.
 template <int MODE, int CB>
-__global__ __launch_bounds__(kEsT) void edge_stream_bwd_kernel(int c, int n, int k, int P, const unsigned *__restrict__ ent,
+__global__ __launch_bounds__(kEsT, 8) void edge_stream_bwd_kernel(int c, int n, int k, int P, const unsigned *__restrict__ ent,
                                                                 const unsigned char *__restrict__ flg,
                                                                 const float *__restrict__ g, float *__restrict__ grad_x) {
     extern __shared__ __attribute__((aligned(16))) float es_f[];  // buf[CB][kEsCE] | bins[CB][n]
@@ -501,19 +535,26 @@ __global__ __launch_bounds__(kEsT) void edge_stream_bwd_kernel(int c, int n, int
     const unsigned *Eb = ent + (size_t)smp * nk;
     const unsigned char *Fb = flg + (size_t)smp * nk;
     for (int i = tid; i < CB * n; i += T) bins[i] = 0.f;
-    auto stage = [&](int row0, size_t e0, int cnt) {  // buf[cc][0 .. cnt) = g[b, row0 + cc, e0 ...]
+    const float *rows[CB];
+#pragma unroll
+    for (int cc = 0; cc < CB; cc++) rows[cc] = g + ((size_t)smp * gc + min(c0 + cc, c - 1)) * nk;  // (a padded channel re-reads the last one; never stored)
+    // 16-byte streaming loads when every row of this workgroup is 16-byte aligned and the chunks are whole float4 groups
+    // (P * k is a multiple of 4, so with n * k a multiple of 4 every chunk is).  Measured and dropped: the rows of chunk
+    // i+1 prefetched into registers during the walk over chunk i (8-wave workgroups at 96-111 VGPRs): 197 us against
+    // 199 us for the gather backward -- the chunk's critical path is the walk's dependent LDS / cross-lane chain, which
+    // more waves per SIMD hide better than a deeper load pipeline (16 waves at <= 64 VGPRs: 182 us).
+    bool vec = (nk & 3) == 0;
+#pragma unroll
+    for (int cc = 0; cc < CB; cc++) vec = vec && (reinterpret_cast<uintptr_t>(rows[cc]) & 15) == 0;
+    auto stage = [&](size_t e0, int cnt) {  // buf[cc][0 .. cnt) = the chunk of row cc
 #pragma unroll
         for (int cc = 0; cc < CB; cc++) {
-            if (c0 + cc >= c) continue;
-            const float *src = g + ((size_t)smp * gc + row0 + cc) * nk + e0;
             float *dst = buf + (size_t)cc * kEsCE;
-            if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-                const int c4 = cnt & ~3;
-                for (int i = tid * 4; i < c4; i += T * 4)
-                    *reinterpret_cast<v4f *>(dst + i) = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(src + i));
-                for (int i = c4 + tid; i < cnt; i += T) dst[i] = src[i];
+            if (vec) {
+                for (int i = tid * 4; i < cnt; i += T * 4)
+                    *reinterpret_cast<v4f *>(dst + i) = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(rows[cc] + e0 + i));
             } else {
-                for (int i = tid; i < cnt; i += T) dst[i] = src[i];
+                for (int i = tid; i < cnt; i += T) dst[i] = rows[cc][e0 + i];
             }
         }
     };
@@ -531,7 +572,7 @@ __global__ __launch_bounds__(kEsT) void edge_stream_bwd_kernel(int c, int n, int
             f_r[gi] = valid ? (unsigned)Fb[e0 + p] : 0u;
         }
         __syncthreads();  // bins zeroed / the previous chunk's buffer fully consumed
-        stage(c0, e0, cnt);
+        stage(e0, cnt);
         __syncthreads();
         // ---- scattered terms: this wave's run of the chunk's target-sorted entries (fetched above, before the staging
         // barrier: inside the loop each group's entry load would be a dependent L2 round trip, ~1.5 us x 7 groups) ----
@@ -592,7 +633,7 @@ __global__ __launch_bounds__(kEsT) void edge_stream_bwd_kernel(int c, int n, int
         }
         if (MODE == 1) {
             __syncthreads();
-            // self terms, first half: bin i loses sum_j g[c][i,j] (one thread per (channel, point): plain updates)
+            // self term of the first half: bin i loses sum_j g[c][i,j] (one thread per (channel, point): plain updates)
             for (int q = tid; q < CB * pc; q += T) {
                 const int cc = q / pc, il = q - cc * pc;
                 const float *row = buf + (size_t)cc * kEsCE + (size_t)il * k;
@@ -600,22 +641,15 @@ __global__ __launch_bounds__(kEsT) void edge_stream_bwd_kernel(int c, int n, int
                 for (int j = 0; j < k; j++) sum += row[j];
                 bins[(size_t)cc * n + i0 + il] -= sum;
             }
-            __syncthreads();
-            stage(c + c0, e0, cnt);
-            __syncthreads();
-            for (int q = tid; q < CB * pc; q += T) {
-                const int cc = q / pc, il = q - cc * pc;
-                const float *row = buf + (size_t)cc * kEsCE + (size_t)il * k;
-                float sum = 0.f;
-                for (int j = 0; j < k; j++) sum += row[j];
-                bins[(size_t)cc * n + i0 + il] += sum;
-            }
         }
     }
     __syncthreads();
     for (int i = tid; i < CB * n; i += T) {
         const int cc = i / n, t = i - cc * n;
-        if (c0 + cc < c) grad_x[((size_t)smp * c + c0 + cc) * n + t] = bins[i];
+        if (c0 + cc < c) {
+            float *dst = grad_x + ((size_t)smp * c + c0 + cc) * n + t;
+            *dst = MODE == 1 ? *dst + bins[i] : bins[i];  // (MODE 1: on top of the second half's self term)
+        }
     }
 }
 
@@ -761,6 +795,23 @@ int edge_stream_bwd(int b, int c, int n, int k, const int64_t *indices, const fl
         pcc::ProfScope prof("edge_chunk_sort_kernel", st);
         hipLaunchKernelGGL(edge_chunk_sort_kernel, dim3((unsigned)pcc::ceil_div(n, P), (unsigned)b), dim3(1024), lds_sort, st, n, k, P,
                            indices, ent, flg);
+    }
+    if (MODE == 1) {
+        const long long wgs = (long long)pcc::ceil_div(n, kSelfPts) * b * c;
+        if (wgs > 0x7fffffffLL) {
+            (void)pcc::ws_free(ws, st);
+            return -1;
+        }
+        static bool attr_self = [] {
+            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(edge_self_sum_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            return ok;
+        }();
+        (void)attr_self;
+        pcc::ProfScope prof("edge_self_sum_kernel", st);
+        hipLaunchKernelGGL(edge_self_sum_kernel, dim3((unsigned)wgs), dim3(256), (size_t)kSelfPts * k * sizeof(float), st, c, n, k, g,
+                           grad_x);
     }
     const dim3 grid((unsigned)(pcc::ceil_div(c, cb) * b));
     {

@@ -33,7 +33,7 @@ for c, k in ((64, 25), (3, 25), (128, 25), (64, 20), (3, 4)):
         L.pcc_graph_features_bwd(B, c, N, k, idx.data_ptr(), g2.data_ptr(), gx.data_ptr(), st)
         L.pcc_gather_neighbours_bwd(B, c, N, k, idx.data_ptr(), g1.data_ptr(), gx.data_ptr(), st)
     torch.cuda.synchronize()
-    for name in (b'edge_chunk_sort_kernel', b'edge_stream_bwd_kernel<features>', b'edge_stream_bwd_kernel<gather>'):
+    for name in (b'edge_chunk_sort_kernel', b'edge_self_sum_kernel', b'edge_stream_bwd_kernel<features>', b'edge_stream_bwd_kernel<gather>'):
         us = ctypes.c_double(); cnt = ctypes.c_int()
         L.pcc_profile_read(name, ctypes.byref(us), ctypes.byref(cnt))
         if cnt.value: print(f'      {name.decode():36s} {us.value:7.1f} us x{cnt.value}')
