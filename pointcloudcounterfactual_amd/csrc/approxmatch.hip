@@ -94,6 +94,7 @@ struct PhaseArgs {
     float w0c;
     float c0, c1;
     float cut2;                        // skip a candidate block when its box is farther than sqrt(cut2)
+    float cut2_fine;                   // pass C/A: the radius of the FINER of its two levels (am_fine_kernel: one exponential beyond it)
     int first;                         // first level: remain* still hold their initial constants
     int level;                         // 0..8 (host bookkeeping only)
     float multiL, multiR;
@@ -207,6 +208,7 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
             a.ratio_in = ratioL; a.ratio_stride = kLevels * nm4;
             const int lc_i = i + 1 < kLevels ? i + 1 : i;
             a.cut2 = kZeroExp / -sc.lc.c[lc_i];  // the coarser of the two levels decides what is 0
+            a.cut2_fine = kZeroExp / -sc.lc.c[i];
             if (i + 1 < kLevels) {
                 a.c1 = sc.lc.c[i + 1];
                 a.ratio_out = sc.lv + (size_t)(i + 1) * nm4;
@@ -670,14 +672,18 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
         if (tid < NBLK) need[tid] = 0;
         // one box test per thread; the surviving blocks of a group are compacted, in order, into its list (the two
         // waves that hold the flags of a group: 2 tg and 2 tg + 1)
-        bool keep = false;
+        bool keep = false, outer_only = false;
         if (tb < nblk) {
             const float4 *cb = reinterpret_cast<const float4 *>(a.cand_box + ((size_t)smp * a.cand_nb + q0 / kBox + tb) * 8);
             const float4 lo = cb[0], hi = cb[1];
             const float dx = fmaxf(fmaxf(glo.x - hi.x, lo.x - ghi.x), 0.f);
             const float dy = fmaxf(fmaxf(glo.y - hi.y, lo.y - ghi.y), 0.f);
             const float dz = fmaxf(fmaxf(glo.z - hi.z, lo.z - ghi.z), 0.f);
-            keep = !(dx * dx + dy * dy + dz * dz > cut2);  // farther: every exponential of the pair of boxes is exactly 0
+            const float bd2 = dx * dx + dy * dy + dz * dz;
+            keep = !(bd2 > cut2);  // farther: every exponential of the pair of boxes is exactly 0
+            // pass C/A walks the radius of the COARSER level; between the two radii the finer level's exponential is
+            // exactly 0 for the whole pair of boxes: such a block is marked and costs one exponential, not two
+            outer_only = NW == 2 && bd2 > a.cut2_fine;
         }
         const unsigned long long bal = __ballot(keep);
         if (lane == 0) wave_cnt[w] = __popcll(bal);
@@ -685,7 +691,7 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
         {
             const int before = (w & 1) ? wave_cnt[w - 1] : 0;
             if (keep) {
-                items[tg][before + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)tb;
+                items[tg][before + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)(tb | (outer_only ? 128 : 0));  // (tb < 128)
                 need[tb] = 1;  // (same value from every writer)
             }
         }
@@ -722,8 +728,16 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
         // reads, 16 distinct addresses per wave) against its four owners in registers -- four independent fma chains
         const int nitems = wave_cnt[2 * og] + wave_cnt[2 * og + 1];
         for (int it = cs; it < nitems; it += 2) {
-            const int ci = __builtin_amdgcn_readfirstlane((int)items[og][it]) * kBox + cl;
-            const float x = lds_c[ci], y = lds_c[CH + ci], z = lds_c[2 * CH + ci], wa = lds_c[3 * CH + ci];
+            const int item = __builtin_amdgcn_readfirstlane((int)items[og][it]);
+            const int ci = (item & 127) * kBox + cl;
+            const float x = lds_c[ci], y = lds_c[CH + ci], z = lds_c[2 * CH + ci];
+            if (NW == 2 && (item & 128)) {  // (wave-uniform) beyond the finer level's radius: its terms are exact zeros
+                const float wb = lds_c[4 * CH + ci];
+#pragma unroll
+                for (int j = 0; j < kFineQ; j++) s1[j] = __builtin_fmaf(fast_exp2(c1 * sq3(x - ox[j], y - oy[j], z - oz[j])), wb, s1[j]);
+                continue;
+            }
+            const float wa = lds_c[3 * CH + ci];
             float wb = 0.f;
             if (NW == 2) wb = lds_c[4 * CH + ci];
 #pragma unroll
@@ -916,14 +930,16 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_persist_kernel(FinePersis
         const float cut2 = a.cut2[MODE == PH_CA ? i + 1 : i];  // the coarser of the two levels decides what is 0
         const float *P = lds_p[ROLE ? 0 : 1];
         if (tid < NBLK) need[tid] = 0;
-        const bool keep = tb < nblk && !((ROLE ? d2_role1 : d2_role0) > cut2);
+        const float bd2 = ROLE ? d2_role1 : d2_role0;
+        const bool keep = tb < nblk && !(bd2 > cut2);
+        const bool outer_only = NW == 2 && bd2 > a.cut2[i];  // beyond the finer level's radius (see am_fine_kernel)
         const unsigned long long bal = __ballot(keep);
         if (lane == 0) wave_cnt[w] = __popcll(bal);
         __syncthreads();
         {
             const int before = (w & 1) ? wave_cnt[w - 1] : 0;
             if (keep) {
-                items[tg][before + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)tb;
+                items[tg][before + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)(tb | (outer_only ? 128 : 0));
                 need[tb] = 1;
             }
         }
@@ -948,8 +964,16 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_persist_kernel(FinePersis
         for (int j = 0; j < kFineQ; j++) s0[j] = s1[j] = 0.f;
         const int nitems = wave_cnt[2 * og] + wave_cnt[2 * og + 1];
         for (int it = cs; it < nitems; it += 2) {
-            const int ci = __builtin_amdgcn_readfirstlane((int)items[og][it]) * kBox + cl;
-            const float x = P[ci], y = P[CH + ci], z = P[2 * CH + ci], wa = lds_w[0][ci];
+            const int item = __builtin_amdgcn_readfirstlane((int)items[og][it]);
+            const int ci = (item & 127) * kBox + cl;
+            const float x = P[ci], y = P[CH + ci], z = P[2 * CH + ci];
+            if (NW == 2 && (item & 128)) {  // (wave-uniform; pass C/A only, whose owners are set1)
+                const float wb = lds_w[1][ci];
+#pragma unroll
+                for (int j = 0; j < kFineQ; j++) s1[j] = __builtin_fmaf(fast_exp2(c1 * sq3(x - ox1[j], y - oy1[j], z - oz1[j])), wb, s1[j]);
+                continue;
+            }
+            const float wa = lds_w[0][ci];
             float wb = 0.f;
             if (NW == 2) wb = lds_w[1][ci];
 #pragma unroll
