@@ -2476,7 +2476,7 @@ int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const
 // while the first half runs on the caller's stream, so that one half's kernels fill the launch / drain bubbles of
 // the other's (each launch is a chain link of ~20 us with 4-8 us of fixed cost).  Fork and join are events on the
 // caller's stream: for the caller the call still is "enqueue on `stream`, no host synchronisation".
-constexpr int kMaxLanes = 2;
+constexpr int kMaxLanes = 4;
 hipStream_t side_stream(int which) {  // which = 0 .. kMaxLanes - 2
     static std::mutex mu;
     static hipStream_t streams[64][kMaxLanes - 1] = {};
@@ -2505,25 +2505,35 @@ hipStream_t side_stream(int which) {  // which = 0 .. kMaxLanes - 2
     return streams[dev][which];
 }
 
-struct ForkJoin {  // side waits for everything enqueued on main so far; at scope exit main waits for side
-    hipStream_t main, side;
+struct ForkJoin {  // the side streams wait for everything enqueued on main so far; at scope exit main waits for them
+    hipStream_t main, side[kMaxLanes - 1] = {};
+    int nside = 0;
     bool ok = false;
-    ForkJoin(hipStream_t m, hipStream_t s) : main(m), side(s) {
+    ForkJoin(hipStream_t m, int want) : main(m) {
+        if (want <= 0) return;
         hipEvent_t ev;
-        if (!side || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
-        ok = hipEventRecord(ev, main) == hipSuccess && hipStreamWaitEvent(side, ev, 0) == hipSuccess;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return;
+        if (hipEventRecord(ev, main) == hipSuccess) {
+            for (int i = 0; i < want && i < kMaxLanes - 1; i++) {
+                hipStream_t s = side_stream(i);
+                if (!s || hipStreamWaitEvent(s, ev, 0) != hipSuccess) break;
+                side[nside++] = s;
+            }
+        }
         (void)hipEventDestroy(ev);  // released once the recorded work has completed
+        ok = nside > 0;
     }
     ~ForkJoin() {
-        if (!ok) return;
-        hipEvent_t ev;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-            (void)hipStreamSynchronize(side);  // cannot order the streams any other way
-            return;
+        for (int i = 0; i < nside; i++) {
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                (void)hipStreamSynchronize(side[i]);  // cannot order the streams any other way
+                continue;
+            }
+            (void)hipEventRecord(ev, side[i]);
+            (void)hipStreamWaitEvent(main, ev, 0);
+            (void)hipEventDestroy(ev);
         }
-        (void)hipEventRecord(ev, side);
-        (void)hipStreamWaitEvent(main, ev, 0);
-        (void)hipEventDestroy(ev);
     }
 };
 
@@ -2644,8 +2654,7 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         Sched sc;
     };
     Lane lanes[kMaxLanes];
-    int nlanes = 1;
-    hipStream_t side = nullptr;
+    int nlanes = 1, want_side = 0;
     if (split_enabled && !dbg_counters && b >= 8 && (long long)b * std::max(n, m) >= 32768) {
         // not while the caller's stream is being captured into a graph: the capture stays a single-stream chain
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -2653,15 +2662,19 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
             (void)hipGetLastError();
             cap = hipStreamCaptureStatusNone;
         }
-        if (cap == hipStreamCaptureStatusNone) side = side_stream(0);
+        if (cap == hipStreamCaptureStatusNone) {
+            want_side = 1;
+            const int t = pcc::tuning(PCC_TUNE_AM_LANES);  // (measurement switch: lane count)
+            if (t >= 1 && t <= kMaxLanes) want_side = t - 1;
+        }
     }
-    ForkJoin fj(st, side);
-    if (fj.ok) nlanes = 2;  // (3 and 4 lanes measured 7-9 % slower: more dependent chains only cost more dispatches)
+    ForkJoin fj(st, want_side);
+    if (fj.ok) nlanes = 1 + fj.nside;
     for (int l = 0; l < nlanes; l++) {
         Lane &ln = lanes[l];
         ln.s0 = (int)((long long)b * l / nlanes);
         ln.bc = (int)((long long)b * (l + 1) / nlanes) - ln.s0;
-        ln.st = l == 0 ? st : fj.side;
+        ln.st = l == 0 ? st : fj.side[l - 1];
         const size_t s0 = (size_t)ln.s0;
         Sched &sc = ln.sc;
         sc = Sched{};
@@ -2684,54 +2697,57 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         if (sc.skip) sc.live_cnt = reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow;
     }
     int rc = PCC_OK;
-    for (int l = 0; l < nlanes && !rc; l++) {
+    auto enqueue_head = [&](int l) -> int {
         const Lane &ln = lanes[l];
         const size_t s0 = (size_t)ln.s0;
-        rc = sort_clouds(ln.bc, L, n, m, xyz1 + s0 * n * 3, xyz2 + s0 * m * 3, const_cast<float *>(ln.sc.soa1),
-                         const_cast<float *>(ln.sc.soa2), reinterpret_cast<int *>(base + L.rank1) + s0 * n,
-                         reinterpret_cast<int *>(base + L.rank2) + s0 * m, reinterpret_cast<int *>(base + L.perm1) + s0 * n,
-                         reinterpret_cast<int *>(base + L.perm2) + s0 * m, const_cast<float *>(ln.sc.box1),
-                         const_cast<float *>(ln.sc.box2), ln.sc.rem, ln.sc.lv,
-                         reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow,
-                         after_sort ? reinterpret_cast<float4 *>(base + L.aos1) + s0 * n : nullptr,
-                         after_sort ? reinterpret_cast<float4 *>(base + L.aos2) + s0 * m : nullptr, ln.st);
+        int r = sort_clouds(ln.bc, L, n, m, xyz1 + s0 * n * 3, xyz2 + s0 * m * 3, const_cast<float *>(ln.sc.soa1),
+                            const_cast<float *>(ln.sc.soa2), reinterpret_cast<int *>(base + L.rank1) + s0 * n,
+                            reinterpret_cast<int *>(base + L.rank2) + s0 * m, reinterpret_cast<int *>(base + L.perm1) + s0 * n,
+                            reinterpret_cast<int *>(base + L.perm2) + s0 * m, const_cast<float *>(ln.sc.box1),
+                            const_cast<float *>(ln.sc.box2), ln.sc.rem, ln.sc.lv,
+                            reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow,
+                            after_sort ? reinterpret_cast<float4 *>(base + L.aos1) + s0 * n : nullptr,
+                            after_sort ? reinterpret_cast<float4 *>(base + L.aos2) + s0 * m : nullptr, ln.st);
         // work that only needs the sorted clouds of this lane's samples (pcc_chamfer_emd: the nearest-neighbour search)
-        if (!rc && after_sort) rc = after_sort(ln.s0, ln.bc, ln.st);
-    }
-    if (rc) return rc;
-
+        if (!r && after_sort) r = after_sort(ln.s0, ln.bc, ln.st);
+        return r;
+    };
+    auto enqueue_pass = [&](int l, int p) -> int {
+        const Lane &ln = lanes[l];
+        int mode, var;
+        const PhaseArgs a = build_phase(ln.sc, p, &mode, &var);
+        switch (mode) {
+        case PH_A: return launch_phase<PH_A>(a, ln.bc, var, ln.st, "approxmatch(A)");
+        case PH_B: return launch_phase<PH_B>(a, ln.bc, var, ln.st, "approxmatch(B)");
+        case PH_CA: return launch_phase<PH_CA>(a, ln.bc, var, ln.st, "approxmatch(CA)");
+        default: return launch_phase<PH_C>(a, ln.bc, var, ln.st, "approxmatch(C)");
+        }
+    };
+    int first_pass[kMaxLanes] = {};
     {
-        // pass p of every lane is enqueued before pass p+1 of any: the streams advance together
-        pcc::ProfScope seq0("am_phase_sequence", lanes[0].st, true);
-        pcc::ProfScope seq1("am_phase_sequence", lanes[nlanes > 1 ? 1 : 0].st, true, nlanes >= 2);
-        // the seven passes of levels 0-2 as one resident launch per lane where the device and the sizes allow it
-        int first_pass[kMaxLanes] = {};
-        for (int l = 0; l < nlanes && !rc; l++) {
-            const int r = launch_fine_resident(lanes[l].sc, lanes[l].bc, lanes[l].st);
-            if (r > 0) rc = r;
-            else if (r == 0) first_pass[l] = kFpPasses;
-        }
-        for (int p = 0; p < sched_phases() && !rc; p++) {
-            for (int l = 0; l < nlanes && !rc; l++) {
-                if (p < first_pass[l]) continue;
-                const Lane &ln = lanes[l];
-                int mode, var;
-                const PhaseArgs a = build_phase(ln.sc, p, &mode, &var);
-                switch (mode) {
-                case PH_A: rc = launch_phase<PH_A>(a, ln.bc, var, ln.st, "approxmatch(A)"); break;
-                case PH_B: rc = launch_phase<PH_B>(a, ln.bc, var, ln.st, "approxmatch(B)"); break;
-                case PH_CA: rc = launch_phase<PH_CA>(a, ln.bc, var, ln.st, "approxmatch(CA)"); break;
-                default: rc = launch_phase<PH_C>(a, ln.bc, var, ln.st, "approxmatch(C)"); break;
-                }
-            }
-        }
+        for (int l = 0; l < nlanes && !rc; l++) rc = enqueue_head(l);
         if (rc) return rc;
-    }
-    // what follows the passes for one lane's samples (the implicit path's pair + finish kernels) goes on that lane's
-    // stream: the lane that finishes its passes first starts at once instead of waiting for the join
-    if (lane_tail) {
-        for (int l = 0; l < nlanes; l++)
-            if (int rc2 = lane_tail(lanes[l].s0, lanes[l].bc, lanes[l].st)) return rc2;
+        {
+            // pass p of every lane is enqueued before pass p+1 of any: the streams advance together
+            pcc::ProfScope seq0("am_phase_sequence", lanes[0].st, true);
+            pcc::ProfScope seq1("am_phase_sequence", lanes[nlanes > 1 ? 1 : 0].st, true, nlanes >= 2);
+            // the seven passes of levels 0-2 as one resident launch per lane where the device and the sizes allow it
+            for (int l = 0; l < nlanes && !rc; l++) {
+                const int r = launch_fine_resident(lanes[l].sc, lanes[l].bc, lanes[l].st);
+                if (r > 0) rc = r;
+                else if (r == 0) first_pass[l] = kFpPasses;
+            }
+            for (int p = 0; p < sched_phases() && !rc; p++)
+                for (int l = 0; l < nlanes && !rc; l++)
+                    if (p >= first_pass[l]) rc = enqueue_pass(l, p);
+            if (rc) return rc;
+        }
+        // what follows the passes for one lane's samples (the implicit path's pair + finish kernels) goes on that lane's
+        // stream: the lane that finishes its passes first starts at once instead of waiting for the join
+        if (lane_tail) {
+            for (int l = 0; l < nlanes; l++)
+                if (int rc2 = lane_tail(lanes[l].s0, lanes[l].bc, lanes[l].st)) return rc2;
+        }
     }
     if (dbg_counters) {
         static int h[kDbgInts];
