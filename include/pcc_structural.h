@@ -57,7 +57,11 @@ int pcc_profile_read(const char *kernel_prefix, double *avg_us, int *launches);
  * Replaces `nndistance` (reference nndistance.cu:125-128; declared structural_loss.cpp:13).
  *   xyz[b,n,3], xyz2[b,m,3] -> result[b,n] = min_k |xyz_j - xyz2_k|^2, result_i[b,n] = argmin
  *   (lowest index on ties), and the same with roles swapped -> result2[b,m], result2_i[b,m].
- * Distances are evaluated as fmaf(dz,dz, fmaf(dx,dx, dy*dy)) on differences (bit-exact vs oracle). */
+ * Distances are evaluated as fmaf(dz,dz, fmaf(dx,dx, dy*dy)) on differences (bit-exact vs oracle).
+ * Non-finite coordinates follow the reference's loop literally (nndistance.cu:26-28,116: `k == 0 || d < best` inside
+ * 512-candidate chunks, chunks merged with `result > best`): a NaN query or a NaN candidate 0 gives NaN / index 0; a NaN
+ * candidate at index 512 c (c >= 1) hides candidates 512 c .. 512 c + 511 from every query; a NaN candidate elsewhere never
+ * wins.  (pcc_chamfer_emd, like the approximate EMD itself, is specified for finite coordinates.) */
 void nndistance(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
                 float *result2, int *result2_i, pcc_stream_t stream);
 int pcc_nndistance(int b, int n, const float *xyz, int m, const float *xyz2, float *result, int *result_i,
