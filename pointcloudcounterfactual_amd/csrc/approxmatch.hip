@@ -604,6 +604,17 @@ constexpr int kFineOG = 16;              // owners per culling group (== kBox: t
 constexpr int kFineGroups = 64 / kFineOG;
 constexpr int kFineQ = 4;                // owners per lane
 
+// Sum over the 16 lanes of a DPP row, in every lane of the row: pairs, quads, half rows, rows -- the tree of the xor
+// butterfly (a + b and b + a are the same float), with cross-lane VALU operands instead of four trips through the LDS
+// crossbar (ds_bpermute) per value.
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
 template <int MODE, int CH>
 __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
     constexpr int T = 64 * kFineS;
@@ -752,11 +763,8 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
     // every lane ends with the same sum); lane cl == 0 of each quad hands the four sums to the epilogue
 #pragma unroll
     for (int j = 0; j < kFineQ; j++) {
-#pragma unroll
-        for (int off = 1; off < kBox; off <<= 1) {
-            s0[j] += __shfl_xor(s0[j], off, 64);
-            if (NW == 2) s1[j] += __shfl_xor(s1[j], off, 64);
-        }
+        s0[j] = row_sum16(s0[j]);
+        if (NW == 2) s1[j] = row_sum16(s1[j]);
     }
     if (cl == 0) {
 #pragma unroll
@@ -985,11 +993,8 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_persist_kernel(FinePersis
         }
 #pragma unroll
         for (int j = 0; j < kFineQ; j++) {
-#pragma unroll
-            for (int off = 1; off < kBox; off <<= 1) {
-                s0[j] += __shfl_xor(s0[j], off, 64);
-                if (NW == 2) s1[j] += __shfl_xor(s1[j], off, 64);
-            }
+            s0[j] = row_sum16(s0[j]);
+            if (NW == 2) s1[j] = row_sum16(s1[j]);
         }
         if (cl == 0) {
 #pragma unroll
