@@ -643,6 +643,20 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
     const float *W0 = W0_CONST ? nullptr : a.w0 + (size_t)smp * a.w0_stride;
     const float *W1 = (NW == 2) ? a.w1 + (size_t)smp * a.w1_stride : nullptr;
 
+    // debug stamps as in am_phase_body (PCC_AM_DEBUG=2): [1] owners + boxes loaded, [2] lists built, [3] candidates staged,
+    // [4] walk done, [5] reduced, [6] end
+    unsigned long long tst0 = 0;
+    int *stamp = nullptr;
+    if (a.stamp && threadIdx.x == 0) {
+        const unsigned bx = blockIdx.x, gx = gridDim.x;
+        const int which = bx == 0 ? 0 : bx == gx / 2 ? 1 : bx == gx - 1 ? 2 : -1;
+        if (which >= 0) {
+            stamp = a.stamp + 8 * which;
+            tst0 = __builtin_amdgcn_s_memrealtime();
+            stamp[0] = (int)(tst0 & 0x7fffffff);
+        }
+    }
+#define PCC_STF(k) do { if (stamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[(k)] = (int)(__builtin_amdgcn_s_memrealtime() - tst0); } } while (0)
     float ox[kFineQ], oy[kFineQ], oz[kFineQ], s0[kFineQ], s1[kFineQ];
 #pragma unroll
     for (int j = 0; j < kFineQ; j++) {
@@ -674,6 +688,7 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
         }
     }
     const float c0 = a.c0, c1 = a.c1, cut2 = a.cut2;
+    PCC_STF(1);
 
     for (int q0 = 0; q0 < a.n_cand; q0 += CH) {
         const int cnt = min(CH, a.n_cand - q0);
@@ -707,6 +722,7 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
             }
         }
         __syncthreads();
+        PCC_STF(2);
         {   // stage the blocks some group of this workgroup needs (on the fine levels a fraction of the cloud): the sorted
             // SoA rows and weight rows are padded to a multiple of 4 (zeros), so these are straight float4 copies
             float4 *dst4 = reinterpret_cast<float4 *>(lds_c);
@@ -735,6 +751,7 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
             }
         }
         __syncthreads();
+        PCC_STF(3);
         // a wave walks its half of the group's block list: a lane holds ONE candidate of the block (five scalar LDS
         // reads, 16 distinct addresses per wave) against its four owners in registers -- four independent fma chains
         const int nitems = wave_cnt[2 * og] + wave_cnt[2 * og + 1];
@@ -759,6 +776,7 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
             }
         }
     }
+    PCC_STF(4);
     // the 16 candidate lanes of an owner meet through four butterfly steps (a + b is the same float on both sides, so
     // every lane ends with the same sum); lane cl == 0 of each quad hands the four sums to the epilogue
 #pragma unroll
@@ -774,6 +792,7 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
         }
     }
     __syncthreads();
+    PCC_STF(5);
     if (own_e < 0) return;
     const float sum0 = red[0][0][tid] + red[0][1][tid];
     const float sum1 = NW == 2 ? red[NW - 1][0][tid] + red[NW - 1][1][tid] : 0.f;
@@ -800,6 +819,8 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
         // pass A of the next level: ratioL' = remainL / (1e-9 + sum_l e'*remainR[l])       :37,61
         if (MODE == PH_CA) a.ratio_out[(size_t)smp * a.ratio_stride + own_e] = left / (1e-9f + sum1);
     }
+    PCC_STF(6);
+#undef PCC_STF
 }
 
 // ---------------------------------------------------------------------------------------------------
