@@ -616,7 +616,12 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 template <int MODE, int CH>
-__global__ __launch_bounds__(64 * kFineS) void am_fine_kernel(PhaseArgs a) {
+// (<= 64 VGPRs for passes A and B: with their 34 KB of LDS four workgroups -- the 2 x 512 of the two half-batch lanes --
+// then fit a CU together; at 70 VGPRs three fitted, a quarter of every launch's workgroups waited for a slot, and these
+// launches are bound by a workgroup's own critical path: 445 -> 439 us per match_cost call, A/B across library builds.
+// Pass C/A keeps its 81 registers and 43 KB -- three per CU: its second weight row read from global memory instead of
+// LDS, to fit four, measured 454 us.)
+__global__ __launch_bounds__(64 * kFineS, MODE == PH_CA ? 4 : 8) void am_fine_kernel(PhaseArgs a) {
     constexpr int T = 64 * kFineS;
     constexpr int NW = (MODE == PH_CA) ? 2 : 1;
     constexpr bool W0_CONST = (MODE == PH_A);
