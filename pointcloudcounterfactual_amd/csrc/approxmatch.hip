@@ -247,7 +247,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
     static_assert(VAR == V_PLAIN || COWN || CLIST, "the box-culled passes run on am_fine_kernel");
     static_assert(!(CLIST && W0_CONST), "pass A of the first level has constant weights");
     static_assert(TQ <= T, "one epilogue owner per thread");
-    using L = PhaseLds<2, R, S, CH>;  // offsets do not depend on NW so that every phase sees the same carve
+    using L = PhaseLds<NW, R, S, CH>;  // (four candidate rows for the single-weight passes: 36 KB, four workgroups per CU)
     float *lds_c = smem;                               // x | y | z | w0 | (w1)
     float *red = smem + L::kC;                         // [NW][S][TQ]
     int *own_idx = reinterpret_cast<int *>(red + L::kRed);
@@ -559,7 +559,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
 
 template <int MODE, int R, int S, int CH, int VAR, int G = 1>
 __global__ __launch_bounds__(64 * S) void am_phase_kernel(PhaseArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[PhaseLds<2, R, S, CH>::floats];
+    __shared__ __attribute__((aligned(16))) float smem[PhaseLds<(MODE == PH_CA ? 2 : 1), R, S, CH>::floats];
     // V_COWN packs the live owners into the low tiles: dispatch those first (tile-major order), so the workgroups
     // that have nothing to do and exit after the scan are not in front of the ones that carry the launch
     constexpr bool COWN = VAR == V_COWN;
