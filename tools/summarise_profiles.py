@@ -39,7 +39,11 @@ def short(name: str) -> str:
 
 def one(pattern: str) -> str | None:
     files = glob.glob(os.path.join(G, pattern))  # (a profiled command that starts children leaves one file per process)
-    return max(files, key=os.path.getsize) if files else None
+    if not files:
+        return None
+    newest = max(os.path.getmtime(f) for f in files)  # (a directory may hold an earlier run of the same tag)
+    recent = [f for f in files if newest - os.path.getmtime(f) < 120]
+    return max(recent, key=os.path.getsize)
 
 
 stats = one(f'{tag}_stats/*/*kernel_stats.csv')
