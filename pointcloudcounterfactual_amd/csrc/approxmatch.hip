@@ -2333,6 +2333,9 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
 
 // ---- host side -------------------------------------------------------------------------------------
 constexpr int kPhCH = 2048;
+// the dense list of pass C/A holds the LIVE candidates only (under half of the cloud from level 3 on): chunks of 1024
+// (25-29 KB of LDS: five or six workgroups per CU instead of three; a longer list takes a second chunk)
+constexpr int kClistCH = 1024;
 
 static bool cull_enabled() {  // measurement switch (pcc_test_hooks.h): every work-skipping variant off
     return pcc::tuning(PCC_TUNE_AM_NOCULL) == 0;
@@ -2362,7 +2365,7 @@ int launch_phase_rs(PhaseArgs a, int b, int var, hipStream_t st, const char *wha
         const dim3 g((unsigned)grid), blk(64 * S);
         // only the combinations the schedule uses are instantiated
         if (var == V_CLIST && (MODE == PH_CA || MODE == PH_C))
-            hipLaunchKernelGGL((am_phase_kernel<(MODE == PH_CA || MODE == PH_C) ? MODE : PH_C, R, S, kPhCH, V_CLIST>), g, blk, 0, st, a);
+            hipLaunchKernelGGL((am_phase_kernel<(MODE == PH_CA || MODE == PH_C) ? MODE : PH_C, R, S, kClistCH, V_CLIST>), g, blk, 0, st, a);
         else if (var == V_COWN && MODE == PH_B)
             hipLaunchKernelGGL((am_phase_kernel<PH_B, (G > 1 ? 1 : R), S, kPhCH, V_COWN, G>), g, blk, 0, st, a);
         else hipLaunchKernelGGL((am_phase_kernel<MODE, R, S, kPhCH, V_PLAIN>), g, blk, 0, st, a);
@@ -2402,6 +2405,10 @@ int launch_phase(const PhaseArgs &a, int b, int var, hipStream_t st, const char 
     // (A large batch arrives here as two concurrent half-batch lanes: 32768 owners per launch at B=32, N=2048, where
     // 128-owner tiles measured 492 us per forward+backward against 509 us for 64-owner tiles.)
     const long long owners = (long long)b * a.n_own;
+    // pass C/A on the dense list of live candidates: 25 KB of LDS per 64-owner workgroup (chunks of kClistCH), so the
+    // 2 x 512 workgroups of two half-batch lanes are resident together and every owner's loop is half as long as on the
+    // 128-owner tile (432.9 -> 429.1 us per match_cost call; with the 45 KB carve of 2048-candidate chunks it measured slower)
+    if (var == V_CLIST && owners < 4LL * 65536) return launch_phase_rs<MODE, 1, 8>(a, b, var, st, what);
     if (owners >= 4LL * 65536) return launch_phase_rs<MODE, 4, 8>(a, b, var, st, what);
     if (owners >= 32768) return launch_phase_rs<MODE, 2, 8>(a, b, var, st, what);
     return launch_phase_rs<MODE, 1, 8>(a, b, var, st, what);
