@@ -127,50 +127,42 @@ def timed_steps(recon_t, ref_t, steps: int, warmup: int) -> float:
     return (time.perf_counter() - t0) / steps
 
 
-class KernelTimer:
-    """HIP-event timing of individual launch sequences on the stream they run on (second, instrumented pass)."""
-
-    def __init__(self) -> None:
-        self.records: dict[str, list] = {}
-
-    def time(self, name: str, fn) -> None:
-        import torch
-
-        s = torch.cuda.Event(enable_timing=True)
-        e = torch.cuda.Event(enable_timing=True)
-        s.record()
-        fn()
-        e.record()
-        self.records.setdefault(name, []).append((s, e))
-
-    def avg_us(self, name: str) -> float:
-        r = self.records[name]
-        return sum(s.elapsed_time(e) for s, e in r) / len(r) * 1e3
-
-
 def kernel_breakdown(recon_t, ref_t, steps: int) -> dict[str, float]:
-    """Average duration (us) of each C-ABI launch sequence, HIP events on torch's current stream (the
-    stream every kernel of this library is enqueued on)."""
+    """Average duration (us) of each C-ABI launch sequence: HIP events on torch's current stream (the stream every kernel
+    of this library is enqueued on) around `steps` back-to-back calls of the SAME entry point, so that the host runs
+    ahead of the GPU as it does in the timed loop.  (Rounds 1-2 bracketed single calls of different entry points one after
+    the other: after a 50 us Chamfer call the GPU idles while the host enqueues the ~45 launches of an EMD call, and the
+    interval measured the host -- match_cost read 40 us above its steady-state time.)"""
     import torch
 
     from pointcloudcounterfactual_amd import backend
 
-    kt = KernelTimer()
     b, n = recon_t.shape[0], recon_t.shape[1]
     g = torch.full((b, n), 1.0 / n, device=recon_t.device)
-    out: dict[str, object] = {}
-    for _ in range(steps):
-        kt.time('nndistance', lambda: out.__setitem__('nn', backend.NNDistance(recon_t, ref_t)))
-        d1, i1, d2, i2 = out['nn']
-        kt.time('nndistancegrad', lambda: backend.NNDistanceGrad(recon_t, ref_t, i1, i2, g, g))
-        kt.time('match_cost_implicit_fwd_bwd', lambda: backend.MatchCostImplicit(recon_t, ref_t, True))
-        kt.time('match_cost_implicit_fwd_only', lambda: backend.MatchCostImplicit(recon_t, ref_t, False))
-        kt.time('approxmatch_cost', lambda: out.__setitem__('am', backend.ApproxMatchCost(recon_t, ref_t)))
-        match = out['am'][0]
-        kt.time('matchcostgrad', lambda: backend.MatchCostGrad(recon_t, ref_t, match))
-        out['am'] = match = None
-    torch.cuda.synchronize()
-    return {k: kt.avg_us(k) for k in kt.records}
+    d1, i1, d2, i2 = backend.NNDistance(recon_t, ref_t)
+    match = backend.ApproxMatchCost(recon_t, ref_t)[0]
+
+    def ev(fn) -> float:
+        fn()
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(steps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / steps * 1e3
+
+    out = {
+        'nndistance': ev(lambda: backend.NNDistance(recon_t, ref_t)),
+        'nndistancegrad': ev(lambda: backend.NNDistanceGrad(recon_t, ref_t, i1, i2, g, g)),
+        'match_cost_implicit_fwd_bwd': ev(lambda: backend.MatchCostImplicit(recon_t, ref_t, True)),
+        'match_cost_implicit_fwd_only': ev(lambda: backend.MatchCostImplicit(recon_t, ref_t, False)),
+        'matchcostgrad': ev(lambda: backend.MatchCostGrad(recon_t, ref_t, match)),
+    }
+    del match
+    out['approxmatch_cost'] = ev(lambda: backend.ApproxMatchCost(recon_t, ref_t))
+    return out
 
 
 def phase_kernel_time_us(recon_t, ref_t, steps: int) -> tuple[float, int, int]:
