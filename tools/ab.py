@@ -23,11 +23,12 @@ def ev(iters=40, warm=5):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e3
-res = {0: [], 1: []}
+VALUES = tuple(int(x) for x in os.environ.get('AB_VALUES', '0,1').split(','))
+res = {v: [] for v in VALUES}
 for rep in range(6):
-    for v in (0, 1):
+    for v in VALUES:
         assert L.pcc_test_set_tuning(key, v) == 1
         res[v].append(ev())
 L.pcc_test_set_tuning(key, 0)
-for v in (0, 1):
+for v in VALUES:
     r = sorted(res[v]); print(f'switch {key} = {v}: median {r[len(r)//2]:.1f} us  min {r[0]:.1f}  max {r[-1]:.1f}   ({what})')
