@@ -360,21 +360,6 @@ ClusterState *cluster_state() {
     }
     return &c;
 }
-// compute units of the CURRENT device (cached per device: a process may drive several)
-int device_cus() {
-    static std::atomic<int> cache[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    int v = cache[dev].load(std::memory_order_relaxed);
-    if (v == 0) {
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
-            (void)hipGetLastError();
-            v = 0;
-        }
-        cache[dev].store(v, std::memory_order_relaxed);
-    }
-    return v;
-}
 // nonzero if an earlier cluster launch on this device timed out (and clears the word)
 int take_cluster_failure() {
     std::lock_guard<std::mutex> lk(g_cluster_mu);
@@ -403,7 +388,7 @@ int pcc_auction_forward(int b, int n, const float *xyz1, const float *xyz2, floa
     {
         // measurement switch (pcc_test_hooks.h): 1 forces one workgroup per sample, 2..16 forces C
         const int cl_override = pcc::tuning(PCC_TUNE_AUCTION_CLUSTER);
-        const int cus = device_cus();
+        const int cus = pcc::device_cus();
         int C = 1;
         if (cl_override != 1 && n >= 512 && cus > 0) {
             C = cl_override > 1 ? cl_override : 8;

@@ -17,6 +17,7 @@
 //     registers: the (B,N,N) distance matrix never exists in memory.
 #include "pcc_common.hpp"
 #include "pcc_neighbour.h"
+#include "pcc_test_hooks.h"
 #include "topk.hpp"
 
 namespace {
@@ -464,26 +465,28 @@ __global__ __launch_bounds__(256, CP >= 128 ? 2 : 1) void knn_mfma_kernel(int c,
     constexpr int E = CP * TW / T;  // elements per thread per stage
     static_assert(CP * TW % T == 0, "stage size must be a multiple of the workgroup");
     float pre[E], pre_sq = 0.f;
+    // fetch only issues the loads (clamped addresses, nothing consumes the values); the out-of-range select happens at
+    // commit time, behind the MFMAs -- a select next to the load makes the compiler wait for every load where it is issued.
     auto fetch = [&](int t) {
         const int j0 = t * TW;
 #pragma unroll
         for (int i = 0; i < E; i++) {
             const int e = tid + i * T;
             const int ch = e / TW, j = e - ch * TW;
-            const bool ok = ch < c && j0 + j < n;
-            const float v = xb[(size_t)min(ch, c - 1) * n + min(j0 + j, n - 1)];
-            pre[i] = ok ? v : 0.f;
+            pre[i] = xb[(size_t)min(ch, c - 1) * n + min(j0 + j, n - 1)];
         }
-        if (tid < TW) {
-            const float v = sqb[min(j0 + tid, n - 1)];
-            pre_sq = (j0 + tid < n) ? v : __builtin_inff();
-        }
+        pre_sq = sqb[min(j0 + (tid % TW), n - 1)];
     };
-    auto commit = [&](int slot) {
-        float *dst = tile + slot * CP * TW;
+    auto commit = [&](int t) {
+        const int j0 = t * TW;
+        float *dst = tile + (t & 1) * CP * TW;
 #pragma unroll
-        for (int i = 0; i < E; i++) dst[tid + i * T] = pre[i];
-        if (tid < TW) tsq[slot * TW + tid] = pre_sq;
+        for (int i = 0; i < E; i++) {
+            const int e = tid + i * T;
+            const int ch = e / TW, j = e - ch * TW;
+            dst[e] = (ch < c && j0 + j < n) ? pre[i] : 0.f;
+        }
+        if (tid < TW) tsq[(t & 1) * TW + tid] = (j0 + tid < n) ? pre_sq : __builtin_inff();
     };
     // The two half-waves keep separate lists for the same query (lane and lane ^ 32).  Each list alone would keep
     // buffering until ITS K-th distance is beaten; but once both lists hold ceil(K/2) entries <= t, at least K candidates
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256, CP >= 128 ? 2 : 1) void knn_mfma_kernel(int c,
                 tk.offer(d, t * TW + row);
             }
         }
-        if (t + 1 < nstages) commit(slot ^ 1);
+        if (t + 1 < nstages) commit(t + 1);
         __syncthreads();
     }
     tk.flush();
@@ -573,6 +576,321 @@ __global__ __launch_bounds__(256, CP >= 128 ? 2 : 1) void knn_mfma_kernel(int c,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// c >= 4, role-split form of the kernel above for launches that fill the chip with 256-query workgroups.
+//
+// What the selection costs is instructions (tools/issue_bench.hip, tools/mfma_coissue_bench.hip: a wave issues a VALU
+// instruction every 5-8 cycles, a branch costs tens, and MFMAs of one wave and VALU work of another on the same SIMD
+// add up rather than overlap): knn_mfma_kernel spends ~50 k of them per wave of 32 queries, 4/5 in the 5-instructions-
+// per-slot insertion chains of (distance, index) lists split over two half-waves.  Here:
+//   * waves 0-3 ("matrix waves") only run MFMAs: each owns 64 queries = two 32-query accumulator tiles against the
+//     staged 32-candidate tile, and stores the raw inner products of the stage to LDS as [query][candidate] rows --
+//     the transposition the selection needs comes with the store;
+//   * waves 4-7 ("selection waves") own ONE query per lane.  They stage the candidate tiles, and per stage
+//       - test the 32 candidates of their query against a conservative bound of the K-th distance: fma, compare, and
+//         the compare's carry shifted into a 32-bit mask (3 instructions per candidate, no branch, no LDS write);
+//       - visit the set bits: the exact distance in the reference's order from the inner product still in LDS, and
+//         where it beats the K-th distance, ONE v_med3_f32 per slot into a sorted list of distances WITHOUT indices,
+//         plus an 8-byte (distance, index) record appended to the lane's log in global memory (stream-ordered
+//         workspace, [slot][lane]: coalesced);
+//     after the scan the k-th distance tau is final: a log record belongs to the result iff its distance is below
+//     tau, or equals tau and it is among the first (k - #below) such records -- records are in candidate order, which
+//     is the order equal distances are listed in.  The <= k selected records are ranked against the sorted distances
+//     (equal distances: next free slot, in record order) and written out.  A log that nears its capacity is compacted
+//     to the records not above the current K-th distance (fewer than 2K: a record is only written when it enters the
+//     list).
+// One barrier per stage; inner products and candidate tiles are double-buffered.  Same MFMA instruction, same k order
+// and the same distance expression as knn_mfma_kernel: identical results, ties included.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSplitQ = 256;      // queries per workgroup
+constexpr int kSplitPitch = 36;   // floats per query row of one stage (32 + 4: the rows' ds_read_b128 spread over all banks)
+constexpr int kLogCap = 256;      // log records per query (compacted when fewer than 32 are free)
+
+template <int K, int CP>
+constexpr int split_lds_bytes() {
+    constexpr int main_bytes = 2 * CP * 32 * 4 + 3 * 32 * 4 + 2 * kSplitQ * kSplitPitch * 4;
+    constexpr int final_bytes = K * 256 * (8 + 4);  // selected records | output slots
+    return main_bytes > final_bytes ? main_bytes : final_bytes;
+}
+inline size_t split_log_bytes(int b, int n) { return (size_t)b * pcc::ceil_div(n, kSplitQ) * kLogCap * 256 * sizeof(float2); }
+
+// Largest value of a non-negative int over the wave (wave-uniform result).
+__device__ __forceinline__ int wave_max_nonneg(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// An 8-byte log record, read past the L1 (written by this lane earlier, read once).
+__device__ __forceinline__ float2 log_load(const float2 *p) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(p));
+    return float2{v.x, v.y};
+}
+
+template <int K, int CP /* padded channels, multiple of 2, <= 128 */, int dbg = 0>
+__global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k, const float *__restrict__ x,
+                                                             const float *__restrict__ sq, float2 *__restrict__ logs,
+                                                             int64_t *__restrict__ indices) {
+    constexpr int KS = CP / 2;  // MFMA k-steps (32x32x2)
+    constexpr int tile_floats = CP * 32;
+    constexpr int dist_floats = kSplitQ * kSplitPitch;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *tile = reinterpret_cast<float *>(smem);                 // [2][CP][32]
+    float *tsq = tile + 2 * tile_floats;                           // [3][32] (read one stage later than the tile: see commit)
+    float *dist = tsq + 3 * 32;                                    // [2][256][36]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int smp = blockIdx.y;
+    const float *xb = x + (size_t)smp * c * n;
+    const float *sqb = sq + (size_t)smp * n;
+    const int nstages = (n + 31) / 32;
+
+    if (w < 4) {
+        // ---- matrix wave: queries blockIdx.x * 256 + w * 64 + [0, 64)
+        const int half = lane >> 5, col = lane & 31;
+        float bq[2][KS];  // B operand: query[col][k = 2 * ks + half] of the two query tiles
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int q = min(blockIdx.x * kSplitQ + w * 64 + u * 32 + col, n - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                const int ch = 2 * ks + half;
+                bq[u][ks] = ch < c ? xb[(size_t)ch * n + q] : 0.f;
+            }
+        }
+        __syncthreads();  // stage 0 is in LDS
+        for (int t = 0; t < nstages; t++) {
+            const float *cur = tile + (t & 1) * tile_floats;
+            f32x16 acc[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                acc[u] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            constexpr int KB = KS < 8 ? KS : 8;  // A operands are read this many k-steps ahead of their MFMAs
+#pragma unroll
+            for (int ks0 = 0; ks0 < KS; ks0 += KB) {
+                float av[KB];
+#pragma unroll
+                for (int kk = 0; kk < KB; kk++) av[kk] = cur[(2 * (ks0 + kk) + half) * 32 + col];  // candidate[row = col][k]
+#pragma unroll
+                for (int kk = 0; kk < KB; kk++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+                        if constexpr (!(dbg & 4)) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bq[u][ks0 + kk], acc[u], 0, 0, 0);
+            }
+            // accumulator register r of lane (half, col) = candidate row (r & 3) + 8 * (r >> 2) + 4 * half of query col
+            float *drow = dist + (t & 1) * dist_floats;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if constexpr ((dbg & 16) != 0) break;
+                float *qrow = drow + (w * 64 + u * 32 + col) * kSplitPitch + 4 * half;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<float4 *>(qrow + 8 * j) =
+                        float4{acc[u][4 * j], acc[u][4 * j + 1], acc[u][4 * j + 2], acc[u][4 * j + 3]};
+            }
+            __syncthreads();
+        }
+        __syncthreads();  // (the selection waves reuse the stage buffers after this one)
+        return;
+    }
+
+    // ---- selection wave: one query per lane
+    const int ct = tid - 256;
+    int q = blockIdx.x * kSplitQ + ct;
+    const bool q_ok = q < n;
+    q = q_ok ? q : n - 1;
+    const float sq_q = sqb[q];
+    float2 *logp = logs + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kLogCap * 256 + ct;  // record s at logp[s * 256]
+    float ld[K];  // the K smallest distances so far, ascending
+#pragma unroll
+    for (int s2 = 0; s2 < K; s2++) ld[s2] = __builtin_inff();
+    int lcnt = 0;  // records in this lane's log
+    // Pre-test bound on a = |xj|^2 - 2 xi.xj: every a whose distance fl(a + |xi|^2) is below the K-th distance W is
+    // below it (W - |xi|^2 plus 64 times the rounding the sum and this expression can carry; +inf while the list is open).
+    float bound = __builtin_inff();
+    auto refresh_bound = [&]() {
+        const float W = ld[K - 1];
+        bound = (W - sq_q) + ((fabsf(W) + fabsf(sq_q)) * 0x1p-18f + 1e-30f);
+    };
+    auto compact = [&]() {  // keep the records that can still belong to the result (fewer than 2K)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float W = ld[K - 1];
+        const int m = wave_max_nonneg(lcnt);
+        int kept = 0;
+        for (int i = 0; i < m; i++) {
+            if (i < lcnt) {
+                const float2 e = log_load(logp + i * 256);
+                if (e.x <= W) {
+                    logp[kept * 256] = e;
+                    kept++;
+                }
+            }
+        }
+        lcnt = kept;
+    };
+
+    // Tile staging: global -> registers TWO stages ahead -> LDS one stage ahead.  (One stage ahead, every stage waited
+    // out a global-memory round trip -- several microseconds, more than its arithmetic -- before its barrier.)
+    constexpr int E = CP * 32 / 256;  // tile elements per selection thread per stage
+    float pre_a[E], pre_b[E], pre_sq_a = 0.f, pre_sq_b = 0.f;
+    // fetch only issues the loads (clamped addresses, nothing consumes the values); the out-of-range select happens at
+    // commit time, a stage later -- a select next to the load makes the compiler wait for every load where it is issued.
+    auto fetch = [&](int t, float (&pre)[E], float &pre_sq) {
+        const int j = min(t * 32 + (ct & 31), n - 1);
+#pragma unroll
+        for (int i = 0; i < E; i++) pre[i] = xb[(size_t)min((ct >> 5) + i * 8, c - 1) * n + j];
+        pre_sq = sqb[j];
+    };
+    // (the norms of stage t are read by the selection of stage t one iteration after the matrix waves read its tile, while
+    // another selection wave may already commit stage t + 2: three norm buffers, two tiles)
+    auto commit = [&](int t, const float (&pre)[E], float pre_sq) {
+        float *dst = tile + (t & 1) * tile_floats;
+        const bool in = t * 32 + (ct & 31) < n;
+#pragma unroll
+        for (int i = 0; i < E; i++) dst[ct + i * 256] = (in && (ct >> 5) + i * 8 < c) ? pre[i] : 0.f;
+        if (ct < 32) tsq[(t % 3) * 32 + ct] = in ? pre_sq : __builtin_inff();
+    };
+    // screen: the candidates of stage t that may beat the K-th distance, as a bit mask
+    auto screen = [&](int t) -> unsigned {
+        const float *drow = dist + (t & 1) * dist_floats + ct * kSplitPitch;
+        const float *ts = tsq + (t % 3) * 32;
+        unsigned mask = 0;  // candidate e of the stage ends up in bit 31 - e
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(drow + 8 * g);
+            const float4 a1 = *reinterpret_cast<const float4 *>(drow + 8 * g + 4);
+            const float4 n0 = *reinterpret_cast<const float4 *>(ts + 8 * g);
+            const float4 n1 = *reinterpret_cast<const float4 *>(ts + 8 * g + 4);
+            const float dot[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float nj[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float a = __builtin_fmaf(-2.0f, dot[e], nj[e]);  // == (-2*dot) + |xj|^2: the product is exact
+                // mask = 2 * mask + (a < bound): the compare's carry goes straight into the add (false for NaN)
+                asm("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(bound) : "vcc");
+            }
+        }
+        return __builtin_bitreverse32(mask);  // candidate e in bit e: visited in ascending order
+    };
+    // drain: one round per set bit of the fullest lane, straight-line: a lane without a bit offers +inf, and an offer
+    // that does not beat the K-th distance leaves the list as it is (median of two neighbours and something not below
+    // them), so only the log record is conditional -- no list value crosses a branch.
+    auto drain = [&](int t, unsigned mask) {
+        const float *drow = dist + (t & 1) * dist_floats + ct * kSplitPitch;
+        const float *ts = tsq + (t % 3) * 32;
+        if (__any(lcnt > kLogCap - 32)) compact();
+        // (bottom-tested by hand: the compiler does not rotate a loop around a ballot, and copies the whole list on both
+        // sides of a top test)
+        if (__any(mask != 0)) {
+            // (the LDS reads of the NEXT round's candidate are issued before this round's chain)
+            int e = __builtin_ctz(mask | 0x80000000u);
+            float dot = drow[e], nj = ts[e];
+            do {
+                const bool has = mask != 0;
+                mask &= mask - 1;
+                const int e_next = __builtin_ctz(mask | 0x80000000u);
+                const float dot_next = drow[e_next], nj_next = ts[e_next];
+                // reference CPU path: dist = -2*dot ; dist += |xj|^2 (column term) ; dist += |xi|^2 (row term)
+                const float xe = __builtin_fmaf(-2.0f, dot, nj) + sq_q;
+                const float xv = has ? xe : __builtin_inff();  // (never NaN: it passed a < bound with a finite bound)
+                const float W = ld[K - 1];
+                // (in place, tail first: written as asm so that no slot is copied around the loop)
+#pragma unroll
+                for (int s2 = K - 1; s2 > 0; s2--) asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(ld[s2]) : "v"(ld[s2 - 1]), "v"(xv));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(ld[0]) : "v"(xv));
+                if (xv < W) logp[lcnt * 256] = float2{xv, __int_as_float(t * 32 + e)};
+                lcnt += xv < W ? 1 : 0;
+                e = e_next;
+                dot = dot_next;
+                nj = nj_next;
+            } while (__any(mask != 0));
+        }
+        refresh_bound();
+    };
+    auto step = [&](int t, float (&nxt)[E], float &nxt_sq, const float (&cur)[E], float cur_sq) {
+        // (the loads fly during a whole stage; the commit comes BEFORE the rounds: behind the rounds' log stores its wait
+        // for older loads would wait for the stores too)
+        if (t + 2 < nstages) fetch(t + 2, nxt, nxt_sq);
+        const unsigned mask = (t > 0 && !(dbg & 2)) ? screen(t - 1) : 0u;
+        if (t + 1 < nstages) commit(t + 1, cur, cur_sq);
+        if (t > 0 && !(dbg & 1)) drain(t - 1, mask);
+        __syncthreads();
+    };
+    fetch(0, pre_a, pre_sq_a);
+    commit(0, pre_a, pre_sq_a);
+    if (nstages > 1) fetch(1, pre_b, pre_sq_b);
+    __syncthreads();
+    for (int t = 0; t < nstages; t += 2) {
+        step(t, pre_a, pre_sq_a, pre_b, pre_sq_b);
+        if (t + 1 < nstages) step(t + 1, pre_b, pre_sq_b, pre_a, pre_sq_a);
+    }
+    drain(nstages - 1, screen(nstages - 1));
+    __syncthreads();  // every wave is done with the stage buffers
+
+    // ---- the result from the log
+    float2 *sel = reinterpret_cast<float2 *>(smem) + ct;          // [K][256] selected records below tau
+    int *out = reinterpret_cast<int *>(smem + K * 256 * 8) + ct;  // [K][256] candidate of output slot o (-1: empty)
+    if constexpr ((dbg & 8) != 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float tau = ld[0];
+    int below = 0;  // list entries strictly below tau
+#pragma unroll
+    for (int s2 = 1; s2 < K; s2++) tau = (s2 == k - 1) ? ld[s2] : tau;
+#pragma unroll
+    for (int s2 = 0; s2 < K; s2++) {
+        below += (s2 < k && ld[s2] < tau) ? 1 : 0;
+        out[s2 * 256] = -1;
+    }
+    int nsel = 0, ties = below;  // ties: next output slot of a record equal to tau
+    const int m = wave_max_nonneg(lcnt);
+    for (int i0 = 0; i0 < m; i0 += 8) {  // eight records in flight (one at a time, the scan is a chain of memory round trips)
+        float2 rec[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) rec[u] = log_load(logp + min(i0 + u, kLogCap - 1) * 256);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (i0 + u < lcnt) {
+                if (rec[u].x < tau) {
+                    sel[nsel * 256] = rec[u];
+                    nsel++;
+                } else if (rec[u].x == tau && ties < k) {
+                    out[ties * 256] = __float_as_int(rec[u].y);
+                    ties++;
+                }
+            }
+        }
+    }
+    const int ms = wave_max_nonneg(nsel);
+    for (int j = 0; j < ms; j++) {
+        if (j < nsel) {
+            const float2 e = sel[j * 256];
+            int pos = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < K; s2++) pos += ld[s2] < e.x ? 1 : 0;
+            while (out[pos * 256] != -1) pos++;  // equal distances: the next free slot, in record (= candidate) order
+            out[pos * 256] = __float_as_int(e.y);
+        }
+    }
+    // a wave writes the rows of its 64 queries with consecutive lanes on consecutive words
+    __builtin_amdgcn_wave_barrier();
+    const int wq = (w - 4) * 64;  // first local query of this wave
+    const int q0 = blockIdx.x * kSplitQ + wq;
+    const int *wout = reinterpret_cast<const int *>(smem + K * 256 * 8) + wq;
+    int64_t *dst = indices + ((size_t)smp * n + q0) * k;
+    const int total = min(64, n - q0) * k;
+    for (int e = lane; e < total; e += 64) {
+        const int ql = e / k, o = e - ql * k;
+        const int v = wout[o * 256 + ql];
+        dst[e] = (int64_t)((unsigned)v < (unsigned)n ? v : n - 1);  // (an empty slot only when distances are NaN)
+    }
+}
+
 template <int K>
 int launch_small(int b, int c, int n, int k, const float *x, int64_t *indices, hipStream_t st) {
     pcc::ProfScope prof("knn_small_kernel", st);
@@ -587,8 +905,61 @@ void launch_sorted(const KnnSortedArgs &a, hipStream_t st) {
     hipLaunchKernelGGL((knn_sorted_kernel<K, KPREV>), dim3(pcc::ceil_div(waves, kSW)), dim3(64 * kSW), 0, st, a);
 }
 
+struct SqBuf {  // stream-ordered workspace block, freed behind the work enqueued so far
+    float *p = nullptr;
+    hipStream_t st;
+    explicit SqBuf(hipStream_t s) : st(s) {}
+    ~SqBuf() {
+        if (p) (void)pcc::ws_free(p, st);
+    }
+};
+
+template <int K, int CP>
+int launch_split(int b, int c, int n, int k, const float *x, const float *sq, int64_t *indices, hipStream_t st) {
+    constexpr int lds = split_lds_bytes<K, CP>();
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_split_kernel<K, CP>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) {
+        pcc::set_error((int)attr, "knn: cannot reserve the role-split kernel's LDS");
+        return (int)attr;
+    }
+    SqBuf logs(st);  // the selection waves' records (stream-ordered: freed behind the kernel)
+    if (pcc::ws_malloc(reinterpret_cast<void **>(&logs.p), split_log_bytes(b, n), st) != hipSuccess) {
+        logs.p = nullptr;
+        (void)hipGetLastError();
+        pcc::set_error(PCC_ENOMEM, "knn: workspace allocation failed");
+        return PCC_ENOMEM;
+    }
+    pcc::ProfScope prof("knn_mfma_split_kernel", st);
+    const dim3 grid(pcc::ceil_div(n, kSplitQ), b);
+    float2 *lg = reinterpret_cast<float2 *>(logs.p);
+#define PCC_KNN_DBG(D)                                                                                                    \
+    case D:                                                                                                               \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_split_kernel<K, CP, D>),                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                       \
+        hipLaunchKernelGGL((knn_mfma_split_kernel<K, CP, D>), grid, dim3(512), lds, st, c, n, k, x, sq, lg, indices);     \
+        break;
+    if constexpr (K == 25) {
+        switch (pcc::tuning(10)) {
+            PCC_KNN_DBG(1) PCC_KNN_DBG(3) PCC_KNN_DBG(4) PCC_KNN_DBG(7) PCC_KNN_DBG(23) PCC_KNN_DBG(8) PCC_KNN_DBG(31) PCC_KNN_DBG(5)
+            default: hipLaunchKernelGGL((knn_mfma_split_kernel<K, CP>), grid, dim3(512), lds, st, c, n, k, x, sq, lg, indices);
+        }
+    } else {
+        hipLaunchKernelGGL((knn_mfma_split_kernel<K, CP>), grid, dim3(512), lds, st, c, n, k, x, sq, lg, indices);
+    }
+    return PCC_OK;
+}
+
 template <int K>
 int launch_mfma(int b, int c, int n, int k, const float *x, const float *sq, int64_t *indices, hipStream_t st) {
+    // 256-query role-split workgroups once they fill half of the chip (one per CU); the 128-query kernel below that
+    const int sw = pcc::tuning(PCC_TUNE_KNN_NOSPLIT);  // measurement switch: 1 = never, 2 = always
+    if (sw == 2 || (sw == 0 && (long long)pcc::ceil_div(n, kSplitQ) * b * 2 >= pcc::device_cus())) {
+        if (c <= 16) return launch_split<K, 16>(b, c, n, k, x, sq, indices, st);
+        if (c <= 32) return launch_split<K, 32>(b, c, n, k, x, sq, indices, st);
+        if (c <= 64) return launch_split<K, 64>(b, c, n, k, x, sq, indices, st);
+        return launch_split<K, 128>(b, c, n, k, x, sq, indices, st);
+    }
     pcc::ProfScope prof("knn_mfma_kernel", st);
     const dim3 grid(pcc::ceil_div(n, 128), b);
     // two 32-candidate tiles (two accumulator chains) per stage while the double-buffered tiles leave room for two
@@ -600,15 +971,6 @@ int launch_mfma(int b, int c, int n, int k, const float *x, const float *sq, int
     else hipLaunchKernelGGL((knn_mfma_kernel<K, 128, kTT128>), grid, dim3(256), 0, st, c, n, k, x, sq, indices);
     return PCC_OK;
 }
-
-struct SqBuf {
-    float *p = nullptr;
-    hipStream_t st;
-    explicit SqBuf(hipStream_t s) : st(s) {}
-    ~SqBuf() {
-        if (p) (void)pcc::ws_free(p, st);
-    }
-};
 
 }  // namespace
 
@@ -670,11 +1032,13 @@ extern "C" int pcc_knn(int b, int c, int n, int k, const float *x, int64_t *indi
     }
     hipLaunchKernelGGL(sqnorm_kernel, dim3(pcc::ceil_div(n, 256), b), dim3(256), 0, st, c, n, x, sq.p);
     if (int rc = pcc::check_launch("knn(sqnorm)")) return rc;
-    if (k <= 4) launch_mfma<4>(b, c, n, k, x, sq.p, indices, st);
-    else if (k <= 8) launch_mfma<8>(b, c, n, k, x, sq.p, indices, st);
-    else if (k <= 16) launch_mfma<16>(b, c, n, k, x, sq.p, indices, st);
-    else if (k <= 20) launch_mfma<20>(b, c, n, k, x, sq.p, indices, st);
-    else if (k <= 25) launch_mfma<25>(b, c, n, k, x, sq.p, indices, st);
-    else launch_mfma<32>(b, c, n, k, x, sq.p, indices, st);
+    int rc;
+    if (k <= 4) rc = launch_mfma<4>(b, c, n, k, x, sq.p, indices, st);
+    else if (k <= 8) rc = launch_mfma<8>(b, c, n, k, x, sq.p, indices, st);
+    else if (k <= 16) rc = launch_mfma<16>(b, c, n, k, x, sq.p, indices, st);
+    else if (k <= 20) rc = launch_mfma<20>(b, c, n, k, x, sq.p, indices, st);
+    else if (k <= 25) rc = launch_mfma<25>(b, c, n, k, x, sq.p, indices, st);
+    else rc = launch_mfma<32>(b, c, n, k, x, sq.p, indices, st);
+    if (rc) return rc;
     return pcc::check_launch("knn(mfma)");
 }

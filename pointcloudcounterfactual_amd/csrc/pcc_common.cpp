@@ -1,6 +1,8 @@
 // Per-thread error record and library info for libpcc_structural.so.
 #include "pcc_common.hpp"
 
+#include <atomic>
+
 #include <mutex>
 #include <string>
 #include <vector>
@@ -15,6 +17,22 @@ int g_tuning[16] = {};
 }
 
 namespace pcc {
+// compute units of the CURRENT device (cached per device: a process may drive several)
+int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int v = cache[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            v = 0;
+        }
+        cache[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 int tuning(int key) { return key >= 0 && key < 16 ? __atomic_load_n(&g_tuning[key], __ATOMIC_RELAXED) : 0; }
 void set_error(int status, const char *what) {
     t_status = status;

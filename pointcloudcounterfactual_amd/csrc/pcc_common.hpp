@@ -42,6 +42,9 @@ __device__ __forceinline__ float sq3(float x, float y, float z) {
 // PCC_TEST_HOOKS=1): the value of switch `key` (0 = the product's behaviour).
 int tuning(int key);
 
+// Compute units of the CURRENT device (cached per device: a process may drive several); 0 if the query fails.
+int device_cus();
+
 // Optional hipEvent bracket around one kernel launch (pcc_profile_* in the C ABI).
 bool profiling();
 struct ProfScope {

@@ -149,15 +149,43 @@ def test_knn_ties_ascending_index(cuda, oracle_mod):
 
 @pytest.mark.parametrize('b,c,n,k', [(2, 4, 64, 4), (2, 6, 200, 16), (2, 64, 257, 25), (1, 64, 2048, 25), (2, 128, 300, 20),
                                        (1, 128, 2048, 25), (2, 17, 131, 8), (2, 64, 2050, 25)])
-def test_knn_mfma_vs_oracle(cuda, oracle_mod, b, c, n, k):
+@pytest.mark.parametrize('kernel', [1, 2])
+def test_knn_mfma_vs_oracle(cuda, oracle_mod, b, c, n, k, kernel):
     """c >= 4: expanded form on the f32 MFMA pipe.  v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain, so the
-    distances (and therefore the sorted index lists) must match the sequential-fma oracle bit for bit."""
-    from pointcloudcounterfactual_amd import neighbour_ops as ops
+    distances (and therefore the sorted index lists) must match the sequential-fma oracle bit for bit -- in the
+    128-query kernel (1) and in the role-split kernel that large launches take (2)."""
+    from pointcloudcounterfactual_amd import _lib, neighbour_ops as ops
 
     x = _x(c * 7 + n, b, c, n)
-    idx = ops.knn(x.to(cuda), k).cpu().numpy()
+    _lib.set_tuning('knn_nosplit', kernel)
+    try:
+        idx = ops.knn(x.to(cuda), k).cpu().numpy()
+    finally:
+        _lib.set_tuning('knn_nosplit', 0)
     exp = oracle_mod.knn_expanded(x.numpy(), k)
     assert np.array_equal(idx, exp)
+
+
+@pytest.mark.parametrize('kernel', [1, 2])
+def test_knn_mfma_adversarial_orders(cuda, oracle_mod, kernel):
+    """Candidate orders that stress the selection: distances descending along the index (every candidate displaces an
+    entry of every list), ascending (the first k stay), exact ties everywhere, and a query count that leaves the last
+    workgroup mostly empty."""
+    from pointcloudcounterfactual_amd import _lib, neighbour_ops as ops
+
+    n, c = 700, 5
+    t = torch.linspace(0, 1, n)
+    line = torch.stack([t, 2 * t, -t, 0.5 * t, t * t], 0)[None]                      # points along a curve, in index order
+    rev = line.flip(2)
+    ties = torch.cat([_x(11, 1, c, 70)] * 10, dim=2)                                 # every point ten times
+    for x, k in ((line, 25), (rev, 25), (ties, 16), (torch.cat([line, rev, ties], 0), 20)):
+        x = x.contiguous()
+        _lib.set_tuning('knn_nosplit', kernel)
+        try:
+            idx = ops.knn(x.to(cuda), k).cpu().numpy()
+        finally:
+            _lib.set_tuning('knn_nosplit', 0)
+        assert np.array_equal(idx, oracle_mod.knn_expanded(x.numpy(), k))
 
 
 @pytest.mark.parametrize('tag', ['c3', 'c3k20', 'c64'])
