@@ -632,7 +632,7 @@ __device__ __forceinline__ float2 log_load(const float2 *p) {
     return float2{v.x, v.y};
 }
 
-template <int K, int CP /* padded channels, multiple of 2, <= 128 */, int dbg = 0>
+template <int K, int CP /* padded channels, multiple of 2, <= 128 */>
 __global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k, const float *__restrict__ x,
                                                              const float *__restrict__ sq, float2 *__restrict__ logs,
                                                              int64_t *__restrict__ indices) {
@@ -681,13 +681,12 @@ __global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k
                 for (int kk = 0; kk < KB; kk++)
 #pragma unroll
                     for (int u = 0; u < 2; u++)
-                        if constexpr (!(dbg & 4)) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bq[u][ks0 + kk], acc[u], 0, 0, 0);
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bq[u][ks0 + kk], acc[u], 0, 0, 0);
             }
             // accumulator register r of lane (half, col) = candidate row (r & 3) + 8 * (r >> 2) + 4 * half of query col
             float *drow = dist + (t & 1) * dist_floats;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                if constexpr ((dbg & 16) != 0) break;
                 float *qrow = drow + (w * 64 + u * 32 + col) * kSplitPitch + 4 * half;
 #pragma unroll
                 for (int j = 0; j < 4; j++)
@@ -705,7 +704,8 @@ __global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k
     int q = blockIdx.x * kSplitQ + ct;
     const bool q_ok = q < n;
     q = q_ok ? q : n - 1;
-    const float sq_q = sqb[q];
+    float sq_q = sqb[q];
+    asm volatile("" : "+v"(sq_q));  // (consumed here: left pending, its wait lands in the rounds and drains the tile prefetch with it)
     float2 *logp = logs + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kLogCap * 256 + ct;  // record s at logp[s * 256]
     float ld[K];  // the K smallest distances so far, ascending
 #pragma unroll
@@ -718,20 +718,25 @@ __global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k
         const float W = ld[K - 1];
         bound = (W - sq_q) + ((fabsf(W) + fabsf(sq_q)) * 0x1p-18f + 1e-30f);
     };
-    auto compact = [&]() {  // keep the records that can still belong to the result (fewer than 2K)
+    // keep the records that can still belong to the result (fewer than 2K).  Rare; its memory accesses are asm for the
+    // reason given at the log store in drain (a visible load or store here costs every stage of every call a drain of the
+    // tile prefetch), one round trip per record.
+    auto compact = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const float W = ld[K - 1];
         const int m = wave_max_nonneg(lcnt);
         int kept = 0;
         for (int i = 0; i < m; i++) {
             if (i < lcnt) {
-                const float2 e = log_load(logp + i * 256);
-                if (e.x <= W) {
-                    logp[kept * 256] = e;
+                unsigned long long rec;
+                asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(rec) : "v"(logp + i * 256) : "memory");
+                if (__uint_as_float((unsigned)rec) <= W) {
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(logp + kept * 256), "v"(rec) : "memory");
                     kept++;
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lcnt = kept;
     };
 
@@ -752,8 +757,10 @@ __global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k
     auto commit = [&](int t, const float (&pre)[E], float pre_sq) {
         float *dst = tile + (t & 1) * tile_floats;
         const bool in = t * 32 + (ct & 31) < n;
+        // (bit masks, not selects: the compiler turns the selects into a branch per element)
 #pragma unroll
-        for (int i = 0; i < E; i++) dst[ct + i * 256] = (in && (ct >> 5) + i * 8 < c) ? pre[i] : 0.f;
+        for (int i = 0; i < E; i++)
+            dst[ct + i * 256] = __int_as_float(__float_as_int(pre[i]) & -(int)(in && (ct >> 5) + i * 8 < c));
         if (ct < 32) tsq[(t % 3) * 32 + ct] = in ? pre_sq : __builtin_inff();
     };
     // screen: the candidates of stage t that may beat the K-th distance, as a bit mask
@@ -804,7 +811,14 @@ __global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k
 #pragma unroll
                 for (int s2 = K - 1; s2 > 0; s2--) asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(ld[s2]) : "v"(ld[s2 - 1]), "v"(xv));
                 asm volatile("v_min_f32 %0, %0, %1" : "+v"(ld[0]) : "v"(xv));
-                if (xv < W) logp[lcnt * 256] = float2{xv, __int_as_float(t * 32 + e)};
+                if (xv < W) {
+                    // (asm: with a store the compiler can see in this loop, its wait-count pass drains every load in
+                    // flight -- the tile prefetch -- before the loop, once per stage; the explicit waits before the
+                    // log is read back order these stores)
+                    const unsigned long long rec =
+                        ((unsigned long long)(unsigned)(t * 32 + e) << 32) | (unsigned long long)__float_as_uint(xv);
+                    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(logp + lcnt * 256), "v"(rec) : "memory");
+                }
                 lcnt += xv < W ? 1 : 0;
                 e = e_next;
                 dot = dot_next;
@@ -816,15 +830,15 @@ __global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k
     auto step = [&](int t, float (&nxt)[E], float &nxt_sq, const float (&cur)[E], float cur_sq) {
         // (the loads fly during a whole stage; the commit comes BEFORE the rounds: behind the rounds' log stores its wait
         // for older loads would wait for the stores too)
-        if (t + 2 < nstages) fetch(t + 2, nxt, nxt_sq);
-        const unsigned mask = (t > 0 && !(dbg & 2)) ? screen(t - 1) : 0u;
+        fetch(t + 2, nxt, nxt_sq);  // (unconditional, clamped past the end: behind a branch the compiler must wait as if it had not run)
+        const unsigned mask = t > 0 ? screen(t - 1) : 0u;
         if (t + 1 < nstages) commit(t + 1, cur, cur_sq);
-        if (t > 0 && !(dbg & 1)) drain(t - 1, mask);
+        if (t > 0) drain(t - 1, mask);
         __syncthreads();
     };
     fetch(0, pre_a, pre_sq_a);
     commit(0, pre_a, pre_sq_a);
-    if (nstages > 1) fetch(1, pre_b, pre_sq_b);
+    fetch(1, pre_b, pre_sq_b);
     __syncthreads();
     for (int t = 0; t < nstages; t += 2) {
         step(t, pre_a, pre_sq_a, pre_b, pre_sq_b);
@@ -836,7 +850,6 @@ __global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k
     // ---- the result from the log
     float2 *sel = reinterpret_cast<float2 *>(smem) + ct;          // [K][256] selected records below tau
     int *out = reinterpret_cast<int *>(smem + K * 256 * 8) + ct;  // [K][256] candidate of output slot o (-1: empty)
-    if constexpr ((dbg & 8) != 0) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float tau = ld[0];
     int below = 0;  // list entries strictly below tau
@@ -931,30 +944,17 @@ int launch_split(int b, int c, int n, int k, const float *x, const float *sq, in
         return PCC_ENOMEM;
     }
     pcc::ProfScope prof("knn_mfma_split_kernel", st);
-    const dim3 grid(pcc::ceil_div(n, kSplitQ), b);
-    float2 *lg = reinterpret_cast<float2 *>(logs.p);
-#define PCC_KNN_DBG(D)                                                                                                    \
-    case D:                                                                                                               \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_split_kernel<K, CP, D>),                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                       \
-        hipLaunchKernelGGL((knn_mfma_split_kernel<K, CP, D>), grid, dim3(512), lds, st, c, n, k, x, sq, lg, indices);     \
-        break;
-    if constexpr (K == 25) {
-        switch (pcc::tuning(10)) {
-            PCC_KNN_DBG(1) PCC_KNN_DBG(3) PCC_KNN_DBG(4) PCC_KNN_DBG(7) PCC_KNN_DBG(23) PCC_KNN_DBG(8) PCC_KNN_DBG(31) PCC_KNN_DBG(5)
-            default: hipLaunchKernelGGL((knn_mfma_split_kernel<K, CP>), grid, dim3(512), lds, st, c, n, k, x, sq, lg, indices);
-        }
-    } else {
-        hipLaunchKernelGGL((knn_mfma_split_kernel<K, CP>), grid, dim3(512), lds, st, c, n, k, x, sq, lg, indices);
-    }
+    hipLaunchKernelGGL((knn_mfma_split_kernel<K, CP>), dim3(pcc::ceil_div(n, kSplitQ), b), dim3(512), lds, st, c, n, k, x, sq,
+                       reinterpret_cast<float2 *>(logs.p), indices);
     return PCC_OK;
 }
 
 template <int K>
 int launch_mfma(int b, int c, int n, int k, const float *x, const float *sq, int64_t *indices, hipStream_t st) {
-    // 256-query role-split workgroups once they fill half of the chip (one per CU); the 128-query kernel below that
+    // 256-query role-split workgroups (one per CU) once they fill three quarters of the chip; the 128-query kernel below
+    // that (measured at n = 2048, k = 25: B = 32 c = 64 / 128: 286 / 417 us against 372 / 514; B = 16: 287 / 417 against 295 / 362)
     const int sw = pcc::tuning(PCC_TUNE_KNN_NOSPLIT);  // measurement switch: 1 = never, 2 = always
-    if (sw == 2 || (sw == 0 && (long long)pcc::ceil_div(n, kSplitQ) * b * 2 >= pcc::device_cus())) {
+    if (sw == 2 || (sw == 0 && (long long)pcc::ceil_div(n, kSplitQ) * b * 4 >= 3LL * pcc::device_cus())) {
         if (c <= 16) return launch_split<K, 16>(b, c, n, k, x, sq, indices, st);
         if (c <= 32) return launch_split<K, 32>(b, c, n, k, x, sq, indices, st);
         if (c <= 64) return launch_split<K, 64>(b, c, n, k, x, sq, indices, st);

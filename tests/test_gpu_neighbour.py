@@ -148,7 +148,7 @@ def test_knn_ties_ascending_index(cuda, oracle_mod):
 
 
 @pytest.mark.parametrize('b,c,n,k', [(2, 4, 64, 4), (2, 6, 200, 16), (2, 64, 257, 25), (1, 64, 2048, 25), (2, 128, 300, 20),
-                                       (1, 128, 2048, 25), (2, 17, 131, 8), (2, 64, 2050, 25)])
+                                       (1, 128, 2048, 25), (2, 17, 131, 8), (2, 64, 2050, 25), (2, 32, 500, 30)])
 @pytest.mark.parametrize('kernel', [1, 2])
 def test_knn_mfma_vs_oracle(cuda, oracle_mod, b, c, n, k, kernel):
     """c >= 4: expanded form on the f32 MFMA pipe.  v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain, so the
