@@ -295,8 +295,12 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         if (fast) {
 #pragma unroll
             for (int v = 0; v < V4; v++) {
-                rv[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (beg + 4 * v < end) rv[v] = *reinterpret_cast<const float4 *>(rem + beg + 4 * v);
+                // unconditional, from a clamped address, masked afterwards: behind a branch each of the four loads is a
+                // round trip of its own at the head of the launch
+                const float4 ld = *reinterpret_cast<const float4 *>(rem + min(beg + 4 * v, a.own_n4 - 4));
+                const int keep = -(int)(beg + 4 * v < end);
+                rv[v] = make_float4(__int_as_float(__float_as_int(ld.x) & keep), __int_as_float(__float_as_int(ld.y) & keep),
+                                    __int_as_float(__float_as_int(ld.z) & keep), __int_as_float(__float_as_int(ld.w) & keep));
             }
 #pragma unroll
             for (int v = 0; v < V4; v++)
@@ -373,10 +377,12 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         s1[r] = 0.f;
     }
     // operands of the epilogue do not depend on the pair loop: fetch them now, behind the staging traffic
+    // (for every thread, from a clamped index: issued with the owner coordinates above, one round trip for all)
     float pre_rem = 0.f, pre_ratio = 0.f;
-    if (own_e >= 0) {
-        if (MODE != PH_A && !a.first) pre_rem = a.remain[(size_t)smp * a.remain_stride + own_e];
-        if (MODE == PH_CA || MODE == PH_C) pre_ratio = a.ratio_in[(size_t)smp * a.ratio_stride + own_e];
+    {
+        const int oe = max(own_e, 0);
+        if (MODE != PH_A && !a.first) pre_rem = a.remain[(size_t)smp * a.remain_stride + oe];
+        if (MODE == PH_CA || MODE == PH_C) pre_ratio = a.ratio_in[(size_t)smp * a.ratio_stride + oe];
     }
     PCC_ST(1);
     const float4 *X4 = reinterpret_cast<const float4 *>(lds_c);
@@ -675,10 +681,12 @@ __global__ __launch_bounds__(64 * kFineS, MODE == PH_CA ? 4 : 8) void am_fine_ke
     }
     // epilogue operands (thread e < 64 finishes owner tile * 64 + e): fetched now, behind the staging traffic
     const int own_e = (tid < 64 && tile * 64 + tid < a.n_own) ? tile * 64 + tid : -1;
+    // (for every thread, from a clamped index: issued with the owner coordinates above, one round trip for all)
     float pre_rem = 0.f, pre_ratio = 0.f;
-    if (own_e >= 0) {
-        if (MODE != PH_A && !a.first) pre_rem = a.remain[(size_t)smp * a.remain_stride + own_e];
-        if (MODE == PH_CA || MODE == PH_C) pre_ratio = a.ratio_in[(size_t)smp * a.ratio_stride + own_e];
+    {
+        const int oe = max(own_e, 0);
+        if (MODE != PH_A && !a.first) pre_rem = a.remain[(size_t)smp * a.remain_stride + oe];
+        if (MODE == PH_CA || MODE == PH_C) pre_ratio = a.ratio_in[(size_t)smp * a.ratio_stride + oe];
     }
     // box of the owner group this THREAD tests (thread = (group tg, candidate block tb))
     const int tg = tid / NBLK, tb = tid - tg * NBLK;
@@ -1419,7 +1427,9 @@ __device__ __forceinline__ void bitonic_sort(unsigned (&key)[SLOTS], unsigned *l
 
 template <int SLOTS>
 __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
+    constexpr bool MIRROR = SLOTS <= 8;  // clouds of up to 4096 points keep their coordinates in LDS (48 KB) for the gather
     __shared__ unsigned lds_keys[kSortT * SLOTS];
+    __shared__ float lds_xyz[MIRROR ? 3 * kSortT * SLOTS : 1];
     __shared__ float red[6][16];
     const int which = blockIdx.y;
     const int n = a.n[which], n4 = a.n4[which], nb = a.nb[which], npad = a.npad[which];
@@ -1445,15 +1455,57 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     const unsigned idx_mask = (1u << idx_bits) - 1;
     if (npad) {
         const int code_shift = 30 - 3 * ((32 - idx_bits) / 3);  // keep the leading 3*floor((32-idx_bits)/3) code bits
+        // The thread's points: every load issued before anything consumes one (ONE round trip; read in a loop with the
+        // min/max next to each load, and again for the keys, the kernel waited out eight), kept in registers for the
+        // bounding box and the keys, and mirrored in LDS where the cloud fits, for the gather behind the sort.
+        // (up to 16 slots -- 8192 points -- stay in registers; larger clouds read their points twice, as they come)
+        constexpr bool KEEP = SLOTS <= 16;
+        constexpr int BATCH = SLOTS < 8 ? SLOTS : 8;
+        constexpr int NKEEP = KEEP ? SLOTS : BATCH;
+        float px[NKEEP], py[NKEEP], pz[NKEEP];
+        const int c1 = min(1, nch - 1), c2 = min(2, nch - 1);
+        const int k1 = -(int)(nch > 1), k2 = -(int)(nch > 2);  // channels >= nch read as 0
+        auto load_batch = [&](int s0, int r0) {  // slots s0 .. s0 + BATCH - 1 into registers r0 ..
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {
+                const long long i = min(tid + kSortT * (s0 + u), n - 1);
+                px[r0 + u] = p[i * ps];
+                py[r0 + u] = p[i * ps + c1 * cs];
+                pz[r0 + u] = p[i * ps + c2 * cs];
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {
+                py[r0 + u] = __int_as_float(__float_as_int(py[r0 + u]) & k1);
+                pz[r0 + u] = __int_as_float(__float_as_int(pz[r0 + u]) & k2);
+            }
+        };
         float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()};
         float hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-        for (int i = tid; i < n; i += T)
+        if (!KEEP) {
+            for (int i = tid; i < n; i += T)
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float v = coord(i, c);
-                lo[c] = fminf(lo[c], v);
-                hi[c] = fmaxf(hi[c], v);
+                for (int c = 0; c < 3; c++) {
+                    const float v = coord(i, c);
+                    lo[c] = fminf(lo[c], v);
+                    hi[c] = fmaxf(hi[c], v);
+                }
+        }
+#pragma unroll
+        for (int s0 = 0; s0 < (KEEP ? SLOTS : 0); s0 += BATCH) {
+            const int r0 = s0;
+            load_batch(s0, r0);
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {  // (a slot past the cloud repeats the last point: no effect on the box)
+                lo[0] = fminf(lo[0], px[r0 + u]); hi[0] = fmaxf(hi[0], px[r0 + u]);
+                lo[1] = fminf(lo[1], py[r0 + u]); hi[1] = fmaxf(hi[1], py[r0 + u]);
+                lo[2] = fminf(lo[2], pz[r0 + u]); hi[2] = fmaxf(hi[2], pz[r0 + u]);
+                if (MIRROR) {
+                    lds_xyz[tid + kSortT * (s0 + u)] = px[r0 + u];
+                    lds_xyz[kSortT * SLOTS + tid + kSortT * (s0 + u)] = py[r0 + u];
+                    lds_xyz[2 * kSortT * SLOTS + tid + kSortT * (s0 + u)] = pz[r0 + u];
+                }
             }
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
 #pragma unroll
@@ -1478,15 +1530,30 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
             hi[c] = h > l ? 1023.f / (h - l) : 0.f;  // scale
         }
         unsigned key[SLOTS];
+        if (!KEEP) {
 #pragma unroll
-        for (int s = 0; s < SLOTS; s++) {
-            const int i = tid + kSortT * s;
-            key[s] = ~0u;
-            if (i < n) {
-                const unsigned qx = (unsigned)fminf(fmaxf((coord(i, 0) - lo[0]) * hi[0], 0.f), 1023.f);
-                const unsigned qy = (unsigned)fminf(fmaxf((coord(i, 1) - lo[1]) * hi[1], 0.f), 1023.f);
-                const unsigned qz = (unsigned)fminf(fmaxf((coord(i, 2) - lo[2]) * hi[2], 0.f), 1023.f);
-                key[s] = ((hilbert3(qx, qy, qz) >> code_shift) << idx_bits) | (unsigned)i;
+            for (int s2 = 0; s2 < SLOTS; s2++) {
+                const int i = tid + kSortT * s2;
+                key[s2] = ~0u;
+                if (i < n) {
+                    const unsigned qx = (unsigned)fminf(fmaxf((coord(i, 0) - lo[0]) * hi[0], 0.f), 1023.f);
+                    const unsigned qy = (unsigned)fminf(fmaxf((coord(i, 1) - lo[1]) * hi[1], 0.f), 1023.f);
+                    const unsigned qz = (unsigned)fminf(fmaxf((coord(i, 2) - lo[2]) * hi[2], 0.f), 1023.f);
+                    key[s2] = ((hilbert3(qx, qy, qz) >> code_shift) << idx_bits) | (unsigned)i;
+                }
+            }
+        }
+#pragma unroll
+        for (int s0 = 0; s0 < (KEEP ? SLOTS : 0); s0 += BATCH) {
+            const int r0 = s0;
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {
+                const int i = tid + kSortT * (s0 + u);
+                const unsigned qx = (unsigned)fminf(fmaxf((px[r0 + u] - lo[0]) * hi[0], 0.f), 1023.f);
+                const unsigned qy = (unsigned)fminf(fmaxf((py[r0 + u] - lo[1]) * hi[1], 0.f), 1023.f);
+                const unsigned qz = (unsigned)fminf(fmaxf((pz[r0 + u] - lo[2]) * hi[2], 0.f), 1023.f);
+                const unsigned kv = ((hilbert3(qx, qy, qz) >> code_shift) << idx_bits) | (unsigned)i;
+                key[s0 + u] = i < n ? kv : ~0u;
             }
         }
         bitonic_sort<SLOTS>(key, lds_keys, tid);
@@ -1504,9 +1571,15 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
         const bool real = s < n;
         if (real) {
             const int orig = npad ? (int)(lds_keys[s] & idx_mask) : s;
-            x = coord(orig, 0);
-            y = coord(orig, 1);
-            z = coord(orig, 2);
+            if (MIRROR && npad) {
+                x = lds_xyz[orig];
+                y = lds_xyz[kSortT * SLOTS + orig];
+                z = lds_xyz[2 * kSortT * SLOTS + orig];
+            } else {
+                x = coord(orig, 0);
+                y = coord(orig, 1);
+                z = coord(orig, 2);
+            }
             has_inf |= (__builtin_isinf(x) || __builtin_isinf(y) || __builtin_isinf(z)) ? 1 : 0;
             if (rk) rk[orig] = s;
             pm[s] = orig;
@@ -2325,9 +2398,27 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
     if (i >= npts * 3) return;
     const int s = i / 3, c = i - s * 3;
     const float *p = f.part[which] + (size_t)smp * parts * pitch * 3 + i;
-    float acc = p[0];
-    for (int t = 1; t < parts; t++) acc += p[(size_t)t * pitch * 3];
     const int pt = f.perm[which][(size_t)smp * npts + s];
+    // the partials in the fixed order t = 0, 1, 2 ..., eight loads in flight (one at a time, the fold is a chain of
+    // `parts` memory round trips: most of this kernel's time)
+    const size_t stride = (size_t)pitch * 3;
+    float acc = p[0];
+    int t = 1;
+    for (; t + 8 <= parts; t += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(size_t)(t + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u];
+    }
+    {
+        float v[7];
+#pragma unroll
+        for (int u = 0; u < 7; u++) v[u] = p[(size_t)min(t + u, parts - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 7; u++)
+            if (t + u < parts) acc += v[u];
+    }
     f.out[which][((size_t)smp * npts + pt) * 3 + c] = poisoned ? __builtin_nanf("") : f.scale ? acc * f.scale[smp] : acc;
 }
 
