@@ -328,12 +328,15 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         // an exhausted owner keeps remainR = 0 (and ratioR = 0 from the zero-filled level array): the zero is carried
         // over into the output buffer by the LIVE tiles of the sample, dealt round-robin (tile 0 alone -- the first
         // workgroup of every launch -- used to write all of them: up to 2000 stores on the launch's critical path)
+        // (whole threads -- runs of 16 owners -- are dealt to the tiles: one integer division per thread; per owner it was
+        // 2 of the 4 us this prologue took, PCC_AM_DEBUG=2 stamps)
         const int live_tiles = max(1, (total + TQ - 1) / TQ);
+        const bool carries = (tid % live_tiles) == tile;
         auto place = [&](int i, bool flag) {
             if (flag) {
                 if (pos >= lo && pos < hi) own_idx[pos - lo] = i;
                 pos++;
-            } else if (i < a.n_own && (i % live_tiles) == tile) {
+            } else if (carries && i < a.n_own) {
                 a.remain_out[(size_t)smp * a.remain_stride + i] = 0.f;
             }
         };
