@@ -109,6 +109,9 @@ struct PhaseArgs {
     float *clist;                      // dense candidate list [b][5][cl_n4]: x | y | z | ratioR | remainR (V_COWN writes, V_CLIST reads)
     int *clist_cnt;                    // [b] entries in the list
     int cl_n4;
+    const unsigned *mask_in;           // [b][kLevels][mask_words] bit o of row i: set2 point o is live entering pass B of level i (V_COWN)
+    unsigned *mask_out;                // row i + 1 (pass B of level 2 writes row 3 whole; later ones clear the bits of the owners they exhaust)
+    int mask_words;
     const int *live_in;                // [b] live owners (remain != 0) of this pass B, counted by the previous pass B (V_COWN)
     int *live_out;                     // [b] pass B: live owners of the next level's pass B (integer atomics: order-free)
     int *dbg;                          // optional [2] counters: blocks visited / skipped (debug builds of the host)
@@ -140,6 +143,7 @@ struct Sched {
     float *clist;                  // dense candidate list handed from pass B to pass C/A (null: pass C/A compacts itself)
     int *clist_cnt;
     int *live_cnt;                 // [b][kLiveRow] live set2 points entering pass B of level i (zeroed by the sort; i >= 1)
+    unsigned *live_mask;           // [b][kLevels][ceil(m4 / 32)] live bits of set2 per level (rows 4.. preset to ones by the sort)
     int skip;                      // work-skipping variants enabled
     LevelConsts lc;
     int *dbg;
@@ -190,6 +194,17 @@ __host__ __device__ inline PhaseArgs build_phase(const Sched &sc, int p, int *mo
             a.remain_stride = rs;
             a.ratio_out = ratioR; a.ratio_stride = kLevels * nm4;
             if (var == V_COWN) { a.clist = sc.clist; a.clist_cnt = sc.clist_cnt; a.cl_n4 = sc.m4; }
+            if (sc.live_mask) {
+                const int words = (sc.m4 + 31) / 32;
+                a.mask_words = words;
+                if (i + 1 < kLevels && (var == V_COWN || i == 2)) a.mask_out = sc.live_mask + (size_t)(i + 1) * words;
+                if (var == V_COWN) {
+                    a.mask_in = sc.live_mask + (size_t)i * words;
+                    // liveness comes from the mask, so remainR is updated IN PLACE by its owner from level 3 on (level 2
+                    // left it in the second buffer): an exhausted owner holds 0 from the pass that exhausted it
+                    a.remain = a.remain_out = sc.rem + sc.n4 + sc.m4;
+                }
+            }
             if (sc.live_cnt) {  // strided by kLiveRow ints per sample: the kernels index [smp * kLiveRow]
                 a.live_in = (var == V_COWN && i >= 1) ? sc.live_cnt + i : nullptr;
                 a.live_out = i + 1 < kLevels ? sc.live_cnt + i + 1 : nullptr;
@@ -278,35 +293,47 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
 #define PCC_ST(k) do { if (stamp) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[(k)] = (int)(__builtin_amdgcn_s_memrealtime() - tst0); } } while (0)
     // ---- which owners does this workgroup hold? ----
     if (!COWN && tile * TQ >= a.n_own) return;
+    // Candidate staging, split in two: the loads of a chunk (one float4 group per thread and row: CH / 4 <= T) and its
+    // LDS stores.  The owner-compacted passes issue the loads of the first chunk HERE, above their owner scan, whose
+    // round trips they then share.
+    static_assert(CH / 4 <= T, "one float4 group per thread and chunk");
+    float4 st_x, st_y, st_z, st_0, st_1;
+    auto stage_load = [&](const float *Cc, const float *W0c, const float *W1c, int pitch, int q0, int ngroups) {
+        const int i = min(tid, max(ngroups - 1, 0));  // (clamped: every thread loads, only tid < ngroups stores)
+        st_x = reinterpret_cast<const float4 *>(Cc + q0)[i];
+        st_y = reinterpret_cast<const float4 *>(Cc + (size_t)pitch + q0)[i];
+        st_z = reinterpret_cast<const float4 *>(Cc + (size_t)2 * pitch + q0)[i];
+        st_0 = make_float4(a.w0c, a.w0c, a.w0c, a.w0c);
+        st_1 = st_0;
+        if (!W0_CONST) st_0 = *reinterpret_cast<const float4 *>(W0c + q0 + 4 * i);
+        if (NW == 2) st_1 = *reinterpret_cast<const float4 *>(W1c + q0 + 4 * i);
+    };
+    if (COWN) stage_load(C, W0, W1, a.cand_n4, 0, (min(CH, a.n_cand) + 3) / 4);
     int n_valid = min(TQ, a.n_own - tile * TQ);  // owners of this tile (sorted positions tile*TQ ...)
     if (COWN) {
-        // live owners (remain != 0) of the sample, in order; this workgroup takes the tile-th group of TQ.
-        // Every thread owns a contiguous run of the owner array: one count pass, ONE block scan, one assign pass.
-        const float *rem = a.remain + (size_t)smp * a.remain_stride;
+        // live owners of the sample, in order; this workgroup takes the tile-th group of TQ.  Liveness is one bit per
+        // owner (row `level` of the mask: written whole by pass B of level 2, later rows = the row before with the bits of
+        // the owners exhausted since cleared): a thread takes one 32-owner word -- one count, ONE block scan, and the set
+        // bits of the word dealt to the tile's slots.  (Until round 3 every workgroup scanned the 2048 remainR floats, 16
+        // per thread, and carried the zeros of the exhausted owners into the second remainR buffer: 3-4 us at the head of
+        // each of the six passes, PCC_AM_DEBUG=2 stamps.)
         const int lo = tile * TQ, hi = lo + TQ;
-        // fast path: <= 16 owners per thread, fetched as four independent float4 loads (the rows are padded to a
-        // multiple of 4 with zeros == exhausted) and kept in registers for the assign pass
-        constexpr int V4 = 4;
-        const bool fast = a.own_n4 <= 4 * V4 * T;
-        const int per = fast ? 4 * V4 : (a.n_own + T - 1) / T;
-        const int beg = min(tid * per, fast ? a.own_n4 : a.n_own), end = min(beg + per, fast ? a.own_n4 : a.n_own);
-        float4 rv[V4];
+        const unsigned *mk = a.mask_in + (size_t)smp * kLevels * a.mask_words;
+        unsigned *mnext = (tile == 0 && a.mask_out) ? a.mask_out + (size_t)smp * kLevels * a.mask_words : nullptr;
+        const int wpt = (a.mask_words + T - 1) / T;  // words per thread: 1 up to 32 T = 16384 points
+        unsigned word = 0;
         int mine = 0;
-        if (fast) {
-#pragma unroll
-            for (int v = 0; v < V4; v++) {
-                // unconditional, from a clamped address, masked afterwards: behind a branch each of the four loads is a
-                // round trip of its own at the head of the launch
-                const float4 ld = *reinterpret_cast<const float4 *>(rem + min(beg + 4 * v, a.own_n4 - 4));
-                const int keep = -(int)(beg + 4 * v < end);
-                rv[v] = make_float4(__int_as_float(__float_as_int(ld.x) & keep), __int_as_float(__float_as_int(ld.y) & keep),
-                                    __int_as_float(__float_as_int(ld.z) & keep), __int_as_float(__float_as_int(ld.w) & keep));
-            }
-#pragma unroll
-            for (int v = 0; v < V4; v++)
-                mine += (rv[v].x != 0.f) + (rv[v].y != 0.f) + (rv[v].z != 0.f) + (rv[v].w != 0.f);
+        if (wpt == 1) {
+            word = mk[min(tid, a.mask_words - 1)];
+            word &= -(unsigned)(tid < a.mask_words);
+            if (mnext && tid < a.mask_words) atomicAnd(&mnext[tid], word);  // the next row starts as this one (its preset is all ones)
+            mine = __popc(word);
         } else {
-            for (int i = beg; i < end; i++) mine += rem[i] != 0.f ? 1 : 0;
+            for (int j = tid * wpt; j < min(tid * wpt + wpt, a.mask_words); j++) {
+                const unsigned wj = mk[j];
+                if (mnext) atomicAnd(&mnext[j], wj);
+                mine += __popc(wj);
+            }
         }
         // exclusive scan of `mine` over the workgroup: wave scan + S-entry LDS scan
         int incl = mine;
@@ -324,35 +351,19 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
             before += i < w ? c : 0;
             total += c;
         }
-        int pos = before + incl - mine;
-        // an exhausted owner keeps remainR = 0 (and ratioR = 0 from the zero-filled level array): the zero is carried
-        // over into the output buffer by the LIVE tiles of the sample, dealt round-robin (tile 0 alone -- the first
-        // workgroup of every launch -- used to write all of them: up to 2000 stores on the launch's critical path)
-        // (whole threads -- runs of 16 owners -- are dealt to the tiles: one integer division per thread; per owner it was
-        // 2 of the 4 us this prologue took, PCC_AM_DEBUG=2 stamps)
-        const int live_tiles = max(1, (total + TQ - 1) / TQ);
-        const bool carries = (tid % live_tiles) == tile;
-        auto place = [&](int i, bool flag) {
-            if (flag) {
-                if (pos >= lo && pos < hi) own_idx[pos - lo] = i;
+        int pos = before + incl - mine - lo;  // slot of this thread's first live owner in the tile
+        auto deal = [&](unsigned bits, int first_owner) {
+            while (bits) {
+                const int bit = __builtin_ctz(bits);
+                bits &= bits - 1;
+                if ((unsigned)pos < (unsigned)TQ) own_idx[pos] = first_owner + bit;
                 pos++;
-            } else if (carries && i < a.n_own) {
-                a.remain_out[(size_t)smp * a.remain_stride + i] = 0.f;
             }
         };
-        if (fast) {
-#pragma unroll
-            for (int v = 0; v < V4; v++) {
-                const int i = beg + 4 * v;
-                if (i < end) {
-                    place(i + 0, rv[v].x != 0.f);
-                    place(i + 1, rv[v].y != 0.f);
-                    place(i + 2, rv[v].z != 0.f);
-                    place(i + 3, rv[v].w != 0.f);
-                }
-            }
+        if (wpt == 1) {
+            deal(word, tid * 32);
         } else {
-            for (int i = beg; i < end; i++) place(i, rem[i] != 0.f);
+            for (int j = tid * wpt; j < min(tid * wpt + wpt, a.mask_words); j++) deal(mk[j], j * 32);
         }
         if (a.dbg && tile == 0 && tid == 0) {
             atomicAdd(&a.dbg[0], a.n_own);
@@ -361,6 +372,7 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         if (a.clist_cnt && tile == 0 && tid == 0) a.clist_cnt[smp] = total;  // pass C/A stages exactly the live owners
         n_valid = min(TQ, total - lo);
         if (n_valid <= 0) return;  // wave-uniform: nothing live in this tile
+        (void)hi;
         __syncthreads();
     }
     int own_e = -1;  // sorted position of the owner this THREAD finishes in the epilogue
@@ -407,19 +419,12 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
         int ngroups = (cnt + 3) / 4;
         if (q0) __syncthreads();
         {
-            // sorted SoA rows and the weight rows are padded to a multiple of 4 (zeros): straight float4 copies,
-            // all loads of a thread issued before the first LDS store
+            // sorted SoA rows and the weight rows are padded to a multiple of 4 (zeros): straight float4 copies
             float4 *dst4 = reinterpret_cast<float4 *>(lds_c);
-            const float4 *sx = reinterpret_cast<const float4 *>(C + q0);
-            const float4 *sy = reinterpret_cast<const float4 *>(C + (size_t)cand_pitch + q0);
-            const float4 *sz = reinterpret_cast<const float4 *>(C + (size_t)2 * cand_pitch + q0);
-            const float *sw0 = W0_CONST ? nullptr : W0 + q0;
-            const float *sw1 = NW == 2 ? W1 + q0 : nullptr;
-            for (int i = tid; i < ngroups; i += T) {
-                float4 vx = sx[i], vy = sy[i], vz = sz[i];
-                float4 v0 = make_float4(a.w0c, a.w0c, a.w0c, a.w0c), v1 = v0;
-                if (!W0_CONST) v0 = *reinterpret_cast<const float4 *>(sw0 + 4 * i);
-                if (NW == 2) v1 = *reinterpret_cast<const float4 *>(sw1 + 4 * i);
+            if (!(COWN && q0 == 0)) stage_load(C, W0, W1, cand_pitch, q0, ngroups);
+            const int i = tid;
+            if (i < ngroups) {
+                float4 vx = st_x, vy = st_y, vz = st_z, v0 = st_0, v1 = st_1;
                 if (CLIST && i * 4 + 3 >= cnt) {
                     // the dense list's tail is stale scratch: a padded candidate gets weight 0 below AND finite
                     // coordinates here (0 * exp2(NaN) would be NaN, not the exact 0 a padded candidate must add)
@@ -534,6 +539,8 @@ __device__ __forceinline__ void am_phase_body(const PhaseArgs &a, int smp, int t
                 const unsigned long long alive = __ballot(remain_new != 0.f);
                 if (lane == 0) atomicAdd(&a.live_out[(size_t)smp * kLiveRow], (int)__popcll(alive));
             }
+            if (COWN && a.mask_out && remain_new == 0.f)  // exhausted here: not an owner from the next level on
+                atomicAnd(&a.mask_out[(size_t)smp * kLevels * a.mask_words + (o >> 5)], ~(1u << (o & 31)));
             if (COWN && a.clist) {
                 // this owner is the (tile * TQ + e)-th live one of its sample == its place in the next pass's candidate list
                 float cx = ox[0], cy = oy[0], cz = oz[0];  // thread e = w * 64 + lane holds owner e in slot r = w
@@ -826,6 +833,11 @@ __global__ __launch_bounds__(64 * kFineS, MODE == PH_CA ? 4 : 8) void am_fine_ke
         if (a.live_out) {  // owners still live after this level = the owner count of the next pass B
             const unsigned long long alive = __ballot(remain_new != 0.f);
             if (lane == 0) atomicAdd(&a.live_out[(size_t)smp * kLiveRow], (int)__popcll(alive));
+            if (a.mask_out && lane == 0) {  // ... and their bits: this tile's 64 owners are two whole words of the next row
+                unsigned *mo = a.mask_out + (size_t)smp * kLevels * a.mask_words;
+                if (2 * tile < a.mask_words) mo[2 * tile] = (unsigned)alive;
+                if (2 * tile + 1 < a.mask_words) mo[2 * tile + 1] = (unsigned)(alive >> 32);
+            }
         }
     } else {
         // pass C: suml = sum_l e*ratioL[k]*ratioR[l] ; remainL = max(0, remainL - suml)   :154-162
@@ -877,6 +889,8 @@ struct FinePersistArgs {
     float multiL, multiR;
     float c[4], cut2[4];           // levels 0..3
     int *live_cnt;                 // [b][kLiveRow]
+    unsigned *live_mask;           // [b][kLevels][mask_words] (row 3 is written here: PhaseArgs::mask_out)
+    int mask_words;
     unsigned *host_err;            // sticky word in mapped host memory (or null)
 };
 
@@ -1058,7 +1072,12 @@ __global__ __launch_bounds__(64 * kFineS) void am_fine_persist_kernel(FinePersis
                 remR = remain_new;
                 if (i == 2) {  // owners still live after level 2 = the owner count of pass B of level 3 (V_COWN)
                     const unsigned long long alive = __ballot(remain_new != 0.f);
-                    if (lane == 0) atomicAdd(&row[3], (int)__popcll(alive));
+                    if (lane == 0) {
+                        atomicAdd(&row[3], (int)__popcll(alive));
+                        unsigned *mo = a.live_mask + ((size_t)smp * kLevels + 3) * a.mask_words;  // ... and their bits
+                        if (2 * tile < a.mask_words) mo[2 * tile] = (unsigned)alive;
+                        if (2 * tile + 1 < a.mask_words) mo[2 * tile + 1] = (unsigned)(alive >> 32);
+                    }
                 }
             } else {
                 const float rL = i == 0 ? a.multiL : remL;                               // approxmatch.cu:154-162
@@ -1381,6 +1400,8 @@ struct SortArgs {  // one entry per cloud; blockIdx.y selects it
     float *zero[2];
     long long zero_stride[2], zero_count[2];  // per-sample stride and length in floats (multiples of 4)
     int *live_cnt;                            // [b][kLiveRow] live-owner counters of the passes B, cleared here
+    unsigned *live_mask;                      // [b][kLevels][mask_words] live bits of set2: rows 4.. are preset to ones here
+    int mask_words;
 };
 
 // Bitonic sort of NPAD = kSortT*SLOTS 32-bit keys held in registers (element i = tid + kSortT*slot) by a
@@ -1439,6 +1460,9 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     const int smp = blockIdx.x, tid = threadIdx.x, T = kSortT;
     if (a.live_cnt && which == 0 && (threadIdx.x < kInfSlot || threadIdx.x == kErrSlot))  // (kInfSlot.. are set below)
         a.live_cnt[(size_t)blockIdx.x * kLiveRow + threadIdx.x] = 0;
+    if (a.live_mask && which == 1)  // (rows 4.. of the live masks start as all ones: PhaseArgs::mask_out)
+        for (int i = 4 * a.mask_words + threadIdx.x; i < kLevels * a.mask_words; i += kSortT)
+            a.live_mask[(size_t)blockIdx.x * kLevels * a.mask_words + i] = ~0u;
     if (a.zero[which]) {  // fire-and-forget stores, hidden under the sort
         float4 *z = reinterpret_cast<float4 *>(a.zero[which] + (size_t)smp * a.zero_stride[which]);
         const long long cnt4 = a.zero_count[which] / 4;
@@ -2529,9 +2553,11 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 size_t cost_parts(int n, int m) { return (size_t)pcc::ceil_div(n, kMatKT) * pcc::ceil_div(m, kMatLT); }
 
 // Workspace carve (bytes, every section 16-byte aligned).
+inline int mask_words(int m4) { return (m4 + 31) / 32; }
+
 struct WsLayout {
     int n4, m4, nb1, nb2;
-    size_t soa1, soa2, rank1, rank2, perm1, perm2, box1, box2, rem, lv, lv_orig, cpart, clist, clist_cnt, live_cnt, aos1, aos2, total;
+    size_t soa1, soa2, rank1, rank2, perm1, perm2, box1, box2, rem, lv, lv_orig, cpart, clist, clist_cnt, live_cnt, live_mask, aos1, aos2, total;
     WsLayout(int b, int n, int m) {
         auto up = [](size_t v) { return (v + 15) & ~(size_t)15; };
         n4 = (n + 3) & ~3;
@@ -2554,6 +2580,7 @@ struct WsLayout {
         clist = o; o = up(o + (size_t)b * 5 * m4 * 4);   // dense candidate list handed from pass B to pass C/A
         clist_cnt = o; o = up(o + (size_t)b * 4);
         live_cnt = o; o = up(o + (size_t)b * kLiveRow * 4);
+        live_mask = o; o = up(o + (size_t)b * kLevels * mask_words(m4) * 4);  // live bits of set2 per level (V_COWN)
         aos1 = o; o = up(o + (size_t)b * n * 16);   // packed sorted points for the nearest-neighbour search of pcc_chamfer_emd
         aos2 = o; o = up(o + (size_t)b * m * 16);
         total = o;
@@ -2573,9 +2600,11 @@ void launch_sort(const SortArgs &a, int slots, dim3 grid, hipStream_t st) {
 
 int sort_clouds(int b, const WsLayout &L, int n, int m, const float *xyz1, const float *xyz2, float *soa1, float *soa2,
                 int *rank1, int *rank2, int *perm1, int *perm2, float *box1, float *box2, float *rem, float *lv,
-                int *live_cnt, float4 *aos1, float4 *aos2, hipStream_t st) {
+                int *live_cnt, unsigned *live_mask, float4 *aos1, float4 *aos2, hipStream_t st) {
     SortArgs a{};
     a.live_cnt = live_cnt;
+    a.live_mask = live_mask;
+    a.mask_words = mask_words(L.m4);
     a.aos[0] = aos1; a.aos[1] = aos2;
     // the padded tails of the weight rows are staged as float4: they must be finite (their candidates sit at the
     // origin with these weights), and V_COWN relies on zero-filled level arrays for the exhausted owners it never
@@ -2716,7 +2745,7 @@ static bool resident_enabled() {  // measurement switch (pcc_test_hooks.h): one 
 // the seven fine-level passes of the samples of `sc` as one resident launch; returns -1 when the device / the sizes do
 // not qualify (the caller then runs one launch per pass)
 int launch_fine_resident(const Sched &sc, int bc, hipStream_t st) {
-    if (!sc.skip || !sc.live_cnt || sc.dbg || !resident_enabled()) return -1;
+    if (!sc.skip || !sc.live_cnt || !sc.live_mask || sc.dbg || !resident_enabled()) return -1;
     if (sc.n > kFpCH || sc.m > kFpCH || sc.n < 1 || sc.m < 1) return -1;
     const int tiles = pcc::ceil_div(std::max(sc.n, sc.m), 64);
     FinePersistArgs a{};
@@ -2728,6 +2757,8 @@ int launch_fine_resident(const Sched &sc, int bc, hipStream_t st) {
         a.cut2[i] = kZeroExp / -sc.lc.c[i];
     }
     a.live_cnt = sc.live_cnt;
+    a.live_mask = sc.live_mask;
+    a.mask_words = mask_words(sc.m4);
     {
         std::lock_guard<std::mutex> lk(g_resident_mu);
         ResidentState *r = resident_state();
@@ -2827,6 +2858,7 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
             sc.clist_cnt = reinterpret_cast<int *>(base + L.clist_cnt) + s0;
         }
         if (sc.skip) sc.live_cnt = reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow;
+        if (sc.skip) sc.live_mask = reinterpret_cast<unsigned *>(base + L.live_mask) + s0 * kLevels * mask_words(L.m4);
     }
     int rc = PCC_OK;
     auto enqueue_head = [&](int l) -> int {
@@ -2838,6 +2870,7 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
                             reinterpret_cast<int *>(base + L.perm2) + s0 * m, const_cast<float *>(ln.sc.box1),
                             const_cast<float *>(ln.sc.box2), ln.sc.rem, ln.sc.lv,
                             reinterpret_cast<int *>(base + L.live_cnt) + s0 * kLiveRow,
+                            reinterpret_cast<unsigned *>(base + L.live_mask) + s0 * kLevels * mask_words(L.m4),
                             after_sort ? reinterpret_cast<float4 *>(base + L.aos1) + s0 * n : nullptr,
                             after_sort ? reinterpret_cast<float4 *>(base + L.aos2) + s0 * m : nullptr, ln.st);
         // work that only needs the sorted clouds of this lane's samples (pcc_chamfer_emd: the nearest-neighbour search)

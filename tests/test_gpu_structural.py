@@ -95,7 +95,8 @@ def test_nn_distance_autograd_matches_torch(cuda):
 
 
 AM_SHAPES = [(1, 1, 1), (2, 3, 5), (2, 64, 64), (2, 257, 130), (2, 128, 256), (1, 513, 512), (2, 1024, 1024),
-             (1, 2100, 2300), (1, 4099, 100), (2, 70, 2050)]  # the last three span several 2048-candidate chunks
+             (1, 2100, 2300), (1, 4099, 100), (2, 70, 2050),  # these three span several 2048-candidate chunks
+             (1, 60, 16500)]  # more than 512 words of live bits per sample (two per thread in the owner-compacted passes)
 
 
 @pytest.mark.parametrize('b,n,m', AM_SHAPES)
