@@ -27,6 +27,7 @@ enum {
     PCC_TUNE_NBRSUM_SCATTER = 6,   /* neighbour-sum backward: the per-edge ds_add_f32 scatter */
     PCC_TUNE_AUCTION_CLUSTER = 7,  /* auction: value 1 = one workgroup per sample, 2..16 = that many per sample */
     PCC_TUNE_KNN_NOSPLIT = 8,      /* c >= 4 k-NN: 1 = the 128-query kernel everywhere, 2 = the role-split kernel everywhere */
+    PCC_TUNE_NN_HEAD = 11,         /* pcc_chamfer_emd: every lane searches its nearest neighbours right behind its sort */
     PCC_TUNE_AM_LANES = 9          /* approxmatch: number of half-batch lanes (1..4) instead of 2 */
 };
 int pcc_test_set_tuning(int key, int value);

@@ -103,7 +103,7 @@ def check(status: int, what: str) -> None:
 
 # include/pcc_test_hooks.h: measurement / bit-identity switches (inert unless PCC_TEST_HOOKS=1 is in the environment)
 TUNING = {'pair_plain_order': 1, 'am_nocull': 2, 'am_nosplit': 3, 'am_noresident': 4, 'edge_scatter': 5,
-          'nbrsum_scatter': 6, 'auction_cluster': 7, 'knn_nosplit': 8, 'am_lanes': 9}
+          'nbrsum_scatter': 6, 'auction_cluster': 7, 'knn_nosplit': 8, 'am_lanes': 9, 'nn_head': 11}
 
 
 def set_tuning(name: str, value: int) -> None:

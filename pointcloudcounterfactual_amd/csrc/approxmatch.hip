@@ -2861,6 +2861,7 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         if (sc.skip) sc.live_mask = reinterpret_cast<unsigned *>(base + L.live_mask) + s0 * kLevels * mask_words(L.m4);
     }
     int rc = PCC_OK;
+    const bool nn_all_at_head = pcc::tuning(PCC_TUNE_NN_HEAD) != 0;  // (measurement switch)
     auto enqueue_head = [&](int l) -> int {
         const Lane &ln = lanes[l];
         const size_t s0 = (size_t)ln.s0;
@@ -2873,8 +2874,12 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
                             reinterpret_cast<unsigned *>(base + L.live_mask) + s0 * kLevels * mask_words(L.m4),
                             after_sort ? reinterpret_cast<float4 *>(base + L.aos1) + s0 * n : nullptr,
                             after_sort ? reinterpret_cast<float4 *>(base + L.aos2) + s0 * m : nullptr, ln.st);
-        // work that only needs the sorted clouds of this lane's samples (pcc_chamfer_emd: the nearest-neighbour search)
-        if (!r && after_sort) r = after_sort(ln.s0, ln.bc, ln.st);
+        // work that only needs the sorted clouds of this lane's samples (pcc_chamfer_emd: the nearest-neighbour search).
+        // Even lanes run it here, odd lanes behind their passes: two searches at the same moment halve each other (each
+        // wants every SIMD); against the other lane's pass chain a search costs less (chamfer_emd 447.7 -> 440.4 us, step
+        // 470 -> 462.6 us, tools/ab_nn.py; before passes 3 / 7 / 11 / 15 of the odd lane: 451 / 445 / 445 / 445 us; on a
+        // stream of its own: 522 us).
+        if (!r && after_sort && (l % 2 == 0 || nn_all_at_head)) r = after_sort(ln.s0, ln.bc, ln.st);
         return r;
     };
     auto enqueue_pass = [&](int l, int p) -> int {
@@ -2909,6 +2914,9 @@ int run_levels(int b, int n, int m, const float *xyz1, const float *xyz2, const 
         }
         // what follows the passes for one lane's samples (the implicit path's pair + finish kernels) goes on that lane's
         // stream: the lane that finishes its passes first starts at once instead of waiting for the join
+        if (after_sort && !nn_all_at_head)
+            for (int l = 1; l < nlanes; l += 2)
+                if (int rc2 = after_sort(lanes[l].s0, lanes[l].bc, lanes[l].st)) return rc2;
         if (lane_tail) {
             for (int l = 0; l < nlanes; l++)
                 if (int rc2 = lane_tail(lanes[l].s0, lanes[l].bc, lanes[l].st)) return rc2;
