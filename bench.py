@@ -248,7 +248,7 @@ def other_rows_us(dev) -> dict[str, float]:
     from emd import emdModule
     from pointcloudcounterfactual_amd import neighbour_ops as ops
 
-    def ev(fn, iters=5, warm=2) -> float:
+    def ev(fn, iters=12, warm=3) -> float:
         for _ in range(warm):
             fn()
         s = torch.cuda.Event(enable_timing=True)
