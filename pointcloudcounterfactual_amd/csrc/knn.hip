@@ -954,7 +954,8 @@ int launch_mfma(int b, int c, int n, int k, const float *x, const float *sq, int
     // 256-query role-split workgroups (one per CU) once they fill three quarters of the chip; the 128-query kernel below
     // that (measured at n = 2048, k = 25: B = 32 c = 64 / 128: 286 / 417 us against 372 / 514; B = 16: 287 / 417 against 295 / 362)
     const int sw = pcc::tuning(PCC_TUNE_KNN_NOSPLIT);  // measurement switch: 1 = never, 2 = always
-    if (sw == 2 || (sw == 0 && (long long)pcc::ceil_div(n, kSplitQ) * b * 4 >= 3LL * pcc::device_cus())) {
+    // (and while the selection log -- 512 KB per workgroup -- stays a modest workspace)
+    if (sw == 2 || (sw == 0 && (long long)pcc::ceil_div(n, kSplitQ) * b * 4 >= 3LL * pcc::device_cus() && split_log_bytes(b, n) <= (1ull << 30))) {
         if (c <= 16) return launch_split<K, 16>(b, c, n, k, x, sq, indices, st);
         if (c <= 32) return launch_split<K, 32>(b, c, n, k, x, sq, indices, st);
         if (c <= 64) return launch_split<K, 64>(b, c, n, k, x, sq, indices, st);
