@@ -752,8 +752,11 @@ __global__ __launch_bounds__(64 * kFineS, MODE == PH_CA ? 4 : 8) void am_fine_ke
             const float4 *sx = reinterpret_cast<const float4 *>(C + q0);
             const float4 *sy = reinterpret_cast<const float4 *>(C + (size_t)a.cand_n4 + q0);
             const float4 *sz = reinterpret_cast<const float4 *>(C + (size_t)2 * a.cand_n4 + q0);
-            for (int i = tid; i < nblk * 4; i += T) {
-                if (!need[i >> 2]) continue;
+            // (one float4 group per thread, no loop: as a loop over i += T every row pointer became a 64-bit induction
+            // variable in a VGPR pair, hoisted out of the chunk loop -- most of what pass A / B spilled)
+            static_assert(CH / 4 <= T, "one float4 group per thread and chunk");
+            const int i = tid;
+            if (i < nblk * 4 && need[i >> 2]) {
                 float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vy = vx, vz = vx, v0 = vx, v1 = vx;
                 if (i < ngroups) {
                     vx = sx[i]; vy = sy[i]; vz = sz[i];
@@ -1440,7 +1443,19 @@ __device__ __forceinline__ void bitonic_sort(unsigned (&key)[SLOTS], unsigned *l
 #pragma unroll
                 for (int s = 0; s < SLOTS; s++) {
                     const int i = tid + kSortT * s;
-                    const unsigned other = j >= 64 ? lds[(tid ^ j) + kSortT * s] : (unsigned)__shfl_xor((int)key[s], j, 64);
+                    // the partner lane ^ j: one DPP move for j = 1, 2 (quad permutations) and 8 (a rotation by 8 of the row
+                    // of 16 IS lane ^ 8), two rotations and a select for 4; the LDS crossbar (ds_bpermute) for 16 and 32
+                    unsigned other;
+                    if (j >= 64) other = lds[(tid ^ j) + kSortT * s];
+                    else if (j == 1) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                    else if (j == 2) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+                    else if (j == 8) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0x128, 0xf, 0xf, false);  // row_ror:8
+                    else if (j == 4) {
+                        // (row_ror:n hands lane i the value of lane i - n of its row)
+                        const unsigned lo4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0x124, 0xf, 0xf, false);   // from lane - 4
+                        const unsigned hi4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0x12C, 0xf, 0xf, false);   // from lane - 12 = lane + 4
+                        other = (tid & 4) ? lo4 : hi4;
+                    } else other = (unsigned)__shfl_xor((int)key[s], j, 64);
                     const bool take_min = ((i & j) == 0) == ((i & kk) == 0);
                     key[s] = take_min ? min(key[s], other) : max(key[s], other);
                 }
@@ -1619,15 +1634,17 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
         }
         float l0 = real ? x : __builtin_inff(), l1 = real ? y : __builtin_inff(), l2 = real ? z : __builtin_inff();
         float h0 = real ? x : -__builtin_inff(), h1 = real ? y : -__builtin_inff(), h2 = real ? z : -__builtin_inff();
-#pragma unroll
-        for (int off = 1; off < kBox; off <<= 1) {
-            l0 = fminf(l0, __shfl_xor(l0, off, 64));
-            l1 = fminf(l1, __shfl_xor(l1, off, 64));
-            l2 = fminf(l2, __shfl_xor(l2, off, 64));
-            h0 = fmaxf(h0, __shfl_xor(h0, off, 64));
-            h1 = fmaxf(h1, __shfl_xor(h1, off, 64));
-            h2 = fmaxf(h2, __shfl_xor(h2, off, 64));
-        }
+        // (min / max over the 16 lanes of a DPP row, in every lane: four rotations of the row)
+        auto rot = [](float v, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, false)); };
+        static_assert(kBox == 16, "a box is a DPP row");
+#define PCC_ROW16(op, v)                                                        \
+    v = op(v, rot(v, std::integral_constant<int, 0x128>{}));                    \
+    v = op(v, rot(v, std::integral_constant<int, 0x124>{}));                    \
+    v = op(v, rot(v, std::integral_constant<int, 0x122>{}));                    \
+    v = op(v, rot(v, std::integral_constant<int, 0x121>{}));
+        PCC_ROW16(fminf, l0) PCC_ROW16(fminf, l1) PCC_ROW16(fminf, l2)
+        PCC_ROW16(fmaxf, h0) PCC_ROW16(fmaxf, h1) PCC_ROW16(fmaxf, h2)
+#undef PCC_ROW16
         const int bb = s / kBox;
         if ((s & (kBox - 1)) == 0 && bb < nb) {
             float4 *dst = reinterpret_cast<float4 *>(bx + (size_t)bb * 8);
@@ -2384,8 +2401,22 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(FinishArgs f) {
         if (blockIdx.x) return;
         __shared__ float red2[256];
         float s1 = 0.f, s2 = 0.f;
-        for (int i = tid; i < f.ch_n; i += 256) s1 += f.ch_d1[(size_t)smp * f.ch_n + i];
-        for (int i = tid; i < f.ch_m; i += 256) s2 += f.ch_d2[(size_t)smp * f.ch_m + i];
+        // (eight loads in flight, added in the same order: one at a time this slice was a chain of n / 256 round trips, the
+        // longest of the launch)
+        auto strided_sum = [&](const float *d, int cnt) -> float {
+            float acc = 0.f;
+            for (int i0 = tid; i0 < cnt; i0 += 8 * 256) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = d[min(i0 + u * 256, cnt - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (i0 + u * 256 < cnt) acc += v[u];
+            }
+            return acc;
+        };
+        s1 = strided_sum(f.ch_d1 + (size_t)smp * f.ch_n, f.ch_n);
+        s2 = strided_sum(f.ch_d2 + (size_t)smp * f.ch_m, f.ch_m);
         red[tid] = s1;
         red2[tid] = s2;
         __syncthreads();
