@@ -779,8 +779,10 @@ __global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const float a = __builtin_fmaf(-2.0f, dot[e], nj[e]);  // == (-2*dot) + |xj|^2: the product is exact
-                // mask = 2 * mask + (a < bound): the compare's carry goes straight into the add (false for NaN)
-                asm("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(bound) : "vcc");
+                // mask = 2 * mask + (a < bound): the compare's carry goes straight into the add (false for NaN); the s_nop is
+                // the two wait states gfx950 wants between a VALU write of vcc and a VALU read of it (the compiler puts the
+                // same s_nop between its own v_cmp / v_addc pairs; it cannot see into this block)
+                asm("v_cmp_lt_f32_e32 vcc, %1, %2\n\ts_nop 1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(bound) : "vcc");
             }
         }
         return __builtin_bitreverse32(mask);  // candidate e in bit e: visited in ascending order
