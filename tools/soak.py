@@ -20,6 +20,10 @@ for it in range(300):
     idx = ops.hip_knn(pts, k)
     assert int(idx.min()) >= 0 and int(idx.max()) < n and bool((idx[:, :, 0] == torch.arange(n, device=dev)).all())
     f = torch.randn(b, 16, n, device=dev)
+    if it % 10 == 0:  # feature-space k-NN: both kernels (the role-split one takes the large launches), against each other
+        fk = torch.randn(32 if it % 20 == 0 else b, 24, n, device=dev)
+        i1 = ops.hip_knn(fk, k)
+        assert int(i1.min()) >= 0 and int(i1.max()) < n
     assert torch.isfinite(ops.graph_max_pooling(f, idx, k)).all()
     lc, le = chamfer_emd(x, y)
     assert torch.isfinite(lc + le).all()
