@@ -1407,34 +1407,38 @@ struct SortArgs {  // one entry per cloud; blockIdx.y selects it
     int mask_words;
 };
 
-// Bitonic sort of NPAD = kSortT*SLOTS 32-bit keys held in registers (element i = tid + kSortT*slot) by a
-// 4-wave workgroup: strides >= kSortT are in-register exchanges, strides < 64 are wave shuffles, only the
-// strides 64 and 128 go through LDS (18 cheap 4-wave barriers for 2048 keys).  Fully unrolled so that every
+// Bitonic sort of NPAD = kSortT*SLOTS 32-bit keys held in registers (element i = tid*SLOTS + slot) by an 8-wave
+// workgroup: strides < SLOTS are exchanges between a thread's registers, strides < 64*SLOTS between lanes (DPP where the
+// partner is a quad / row permutation), only the three longest strides go through LDS.  Fully unrolled so that every
 // register index is static.  A key is (truncated Hilbert code << idx_bits) | point index: keys are unique and
 // one v_min_u32 / v_max_u32 pair is a whole compare-exchange.
 constexpr int kSortT = 512;
 
 template <int SLOTS>
 __device__ __forceinline__ void bitonic_sort(unsigned (&key)[SLOTS], unsigned *lds, int tid) {
+    // element tid * SLOTS + s sits in slot s of thread tid (a thread's keys are neighbours): the SHORT strides -- the ones
+    // every merge repeats -- are exchanges between registers, the middle ones between lanes, and only the three longest
+    // strides (6 stages of the 66 at 2048 keys) cross waves through LDS.  (With element tid + 512 s the three strides 64 /
+    // 128 / 256 went through LDS, 12 stages with two barriers each: half of the sort's time by in-kernel stamps.)
     constexpr int NPAD = kSortT * SLOTS;
 #pragma unroll
     for (int kk = 2; kk <= NPAD; kk <<= 1) {
 #pragma unroll
         for (int j = kk >> 1; j > 0; j >>= 1) {
-            if (j >= kSortT) {
-                const int sj = j / kSortT;
+            if (j < SLOTS) {
 #pragma unroll
                 for (int s = 0; s < SLOTS; s++) {
-                    const int sp = s ^ sj;
+                    const int sp = s ^ j;
                     if (sp > s) {
-                        const bool asc = ((tid + kSortT * s) & kk) == 0;
+                        const bool asc = ((tid * SLOTS + s) & kk) == 0;
                         const unsigned mn = min(key[s], key[sp]), mx = max(key[s], key[sp]);
                         key[s] = asc ? mn : mx;
                         key[sp] = asc ? mx : mn;
                     }
                 }
             } else {
-                if (j >= 64) {
+                const int L = j / SLOTS;  // the partner is slot s of thread tid ^ L
+                if (L >= 64) {
                     __syncthreads();
 #pragma unroll
                     for (int s = 0; s < SLOTS; s++) lds[tid + kSortT * s] = key[s];
@@ -1442,21 +1446,20 @@ __device__ __forceinline__ void bitonic_sort(unsigned (&key)[SLOTS], unsigned *l
                 }
 #pragma unroll
                 for (int s = 0; s < SLOTS; s++) {
-                    const int i = tid + kSortT * s;
-                    // the partner lane ^ j: one DPP move for j = 1, 2 (quad permutations) and 8 (a rotation by 8 of the row
+                    // the partner lane ^ L: one DPP move for L = 1, 2 (quad permutations) and 8 (a rotation by 8 of the row
                     // of 16 IS lane ^ 8), two rotations and a select for 4; the LDS crossbar (ds_bpermute) for 16 and 32
                     unsigned other;
-                    if (j >= 64) other = lds[(tid ^ j) + kSortT * s];
-                    else if (j == 1) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-                    else if (j == 2) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-                    else if (j == 8) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0x128, 0xf, 0xf, false);  // row_ror:8
-                    else if (j == 4) {
+                    if (L >= 64) other = lds[(tid ^ L) + kSortT * s];
+                    else if (L == 1) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+                    else if (L == 2) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+                    else if (L == 8) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0x128, 0xf, 0xf, false);  // row_ror:8
+                    else if (L == 4) {
                         // (row_ror:n hands lane i the value of lane i - n of its row)
                         const unsigned lo4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0x124, 0xf, 0xf, false);   // from lane - 4
                         const unsigned hi4 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)key[s], 0x12C, 0xf, 0xf, false);   // from lane - 12 = lane + 4
                         other = (tid & 4) ? lo4 : hi4;
-                    } else other = (unsigned)__shfl_xor((int)key[s], j, 64);
-                    const bool take_min = ((i & j) == 0) == ((i & kk) == 0);
+                    } else other = (unsigned)__shfl_xor((int)key[s], L, 64);
+                    const bool take_min = ((tid & L) == 0) == (((tid * SLOTS + s) & kk) == 0);
                     key[s] = take_min ? min(key[s], other) : max(key[s], other);
                 }
             }
@@ -1510,7 +1513,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
         auto load_batch = [&](int s0, int r0) {  // slots s0 .. s0 + BATCH - 1 into registers r0 ..
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
-                const long long i = min(tid + kSortT * (s0 + u), n - 1);
+                const long long i = min(tid * SLOTS + (s0 + u), n - 1);
                 px[r0 + u] = p[i * ps];
                 py[r0 + u] = p[i * ps + c1 * cs];
                 pz[r0 + u] = p[i * ps + c2 * cs];
@@ -1542,9 +1545,9 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
                 lo[1] = fminf(lo[1], py[r0 + u]); hi[1] = fmaxf(hi[1], py[r0 + u]);
                 lo[2] = fminf(lo[2], pz[r0 + u]); hi[2] = fmaxf(hi[2], pz[r0 + u]);
                 if (MIRROR) {
-                    lds_xyz[tid + kSortT * (s0 + u)] = px[r0 + u];
-                    lds_xyz[kSortT * SLOTS + tid + kSortT * (s0 + u)] = py[r0 + u];
-                    lds_xyz[2 * kSortT * SLOTS + tid + kSortT * (s0 + u)] = pz[r0 + u];
+                    lds_xyz[tid * SLOTS + (s0 + u)] = px[r0 + u];
+                    lds_xyz[kSortT * SLOTS + tid * SLOTS + (s0 + u)] = py[r0 + u];
+                    lds_xyz[2 * kSortT * SLOTS + tid * SLOTS + (s0 + u)] = pz[r0 + u];
                 }
             }
         }
@@ -1575,7 +1578,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
         if (!KEEP) {
 #pragma unroll
             for (int s2 = 0; s2 < SLOTS; s2++) {
-                const int i = tid + kSortT * s2;
+                const int i = tid * SLOTS + s2;
                 key[s2] = ~0u;
                 if (i < n) {
                     const unsigned qx = (unsigned)fminf(fmaxf((coord(i, 0) - lo[0]) * hi[0], 0.f), 1023.f);
@@ -1590,7 +1593,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
             const int r0 = s0;
 #pragma unroll
             for (int u = 0; u < BATCH; u++) {
-                const int i = tid + kSortT * (s0 + u);
+                const int i = tid * SLOTS + (s0 + u);
                 const unsigned qx = (unsigned)fminf(fmaxf((px[r0 + u] - lo[0]) * hi[0], 0.f), 1023.f);
                 const unsigned qy = (unsigned)fminf(fmaxf((py[r0 + u] - lo[1]) * hi[1], 0.f), 1023.f);
                 const unsigned qz = (unsigned)fminf(fmaxf((pz[r0 + u] - lo[2]) * hi[2], 0.f), 1023.f);
@@ -1601,7 +1604,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
         bitonic_sort<SLOTS>(key, lds_keys, tid);
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < SLOTS; s++) lds_keys[tid + kSortT * s] = key[s];
+        for (int s = 0; s < SLOTS; s++) lds_keys[tid * SLOTS + s] = key[s];
         __syncthreads();
     }
     // sorted SoA rows + inverse permutation; the box of every 16 consecutive sorted points falls out of a
