@@ -1553,10 +1553,17 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
+            // (inside the rows of 16 lanes by DPP rotations, across the four rows through the LDS crossbar)
+#define PCC_ROR(v, n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, false))
+            lo[c] = fminf(lo[c], PCC_ROR(lo[c], 8)); hi[c] = fmaxf(hi[c], PCC_ROR(hi[c], 8));
+            lo[c] = fminf(lo[c], PCC_ROR(lo[c], 4)); hi[c] = fmaxf(hi[c], PCC_ROR(hi[c], 4));
+            lo[c] = fminf(lo[c], PCC_ROR(lo[c], 2)); hi[c] = fmaxf(hi[c], PCC_ROR(hi[c], 2));
+            lo[c] = fminf(lo[c], PCC_ROR(lo[c], 1)); hi[c] = fmaxf(hi[c], PCC_ROR(hi[c], 1));
+#undef PCC_ROR
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                lo[c] = fminf(lo[c], __shfl_down(lo[c], off, 64));
-                hi[c] = fmaxf(hi[c], __shfl_down(hi[c], off, 64));
+            for (int off = 16; off < 64; off <<= 1) {
+                lo[c] = fminf(lo[c], __shfl_xor(lo[c], off, 64));
+                hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off, 64));
             }
             if ((tid & 63) == 0) {
                 red[c][tid >> 6] = lo[c];
@@ -1611,7 +1618,7 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
     // 16-lane min/max butterfly on the coordinates the lanes already hold
     const int span = ((max(n4, nb * kBox) + 63) / 64) * 64;
     int has_inf = 0;
-    for (int s = tid; s < span; s += T) {
+    auto emit = [&](int s) {  // sorted position s: its point, its rows, its box
         float x = 0.f, y = 0.f, z = 0.f;
         const bool real = s < n;
         if (real) {
@@ -1654,6 +1661,13 @@ __global__ __launch_bounds__(kSortT) void am_sort_kernel(SortArgs a) {
             dst[0] = make_float4(l0, l1, l2, 0.f);
             dst[1] = make_float4(h0, h1, h2, 0.f);
         }
+    };
+    if (npad && SLOTS <= 8) {  // (unrolled: the LDS reads of all of a thread's positions are in flight together)
+#pragma unroll
+        for (int k2 = 0; k2 < SLOTS; k2++)
+            if (tid + k2 * T < span) emit(tid + k2 * T);  // (span is a multiple of 64: whole waves take the branch)
+    } else {
+        for (int s = tid; s < span; s += T) emit(s);
     }
     // An infinite coordinate makes every pair of its point exp(-inf) = 0 -- skipped here as an exact zero -- while the
     // reference goes on to multiply that 0 by sqrt(inf): its cost and gradients of the sample are NaN (approxmatch.cu:207,
