@@ -864,22 +864,28 @@ __global__ __launch_bounds__(512) void knn_mfma_split_kernel(int c, int n, int k
     }
     int nsel = 0, ties = below;  // ties: next output slot of a record equal to tau
     const int m = wave_max_nonneg(lcnt);
-    for (int i0 = 0; i0 < m; i0 += 8) {  // eight records in flight (one at a time, the scan is a chain of memory round trips)
-        float2 rec[8];
+    // sixteen records in flight: the next eight are loaded before the current eight are looked at (one at a time, the
+    // scan is a chain of memory round trips)
+    float2 cur[8], nxt[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) rec[u] = log_load(logp + min(i0 + u, kLogCap - 1) * 256);
+    for (int u = 0; u < 8; u++) cur[u] = log_load(logp + min(u, kLogCap - 1) * 256);
+    for (int i0 = 0; i0 < m; i0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) nxt[u] = log_load(logp + min(i0 + 8 + u, kLogCap - 1) * 256);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             if (i0 + u < lcnt) {
-                if (rec[u].x < tau) {
-                    sel[nsel * 256] = rec[u];
+                if (cur[u].x < tau) {
+                    sel[nsel * 256] = cur[u];
                     nsel++;
-                } else if (rec[u].x == tau && ties < k) {
-                    out[ties * 256] = __float_as_int(rec[u].y);
+                } else if (cur[u].x == tau && ties < k) {
+                    out[ties * 256] = __float_as_int(cur[u].y);
                     ties++;
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < 8; u++) cur[u] = nxt[u];
     }
     const int ms = wave_max_nonneg(nsel);
     for (int j = 0; j < ms; j++) {
