@@ -166,6 +166,16 @@ def test_knn_mfma_vs_oracle(cuda, oracle_mod, b, c, n, k, kernel):
     assert np.array_equal(idx, exp)
 
 
+def test_knn_mfma_many_small_clouds_take_the_role_split_kernel(cuda, oracle_mod):
+    """A batch of many small clouds fills the chip with 256-query workgroups that are mostly padding (40 of 256 queries,
+    two stages): the product's own dispatch, no switch."""
+    from pointcloudcounterfactual_amd import neighbour_ops as ops
+
+    x = _x(99, 200, 8, 40)
+    idx = ops.knn(x.to(cuda), 5).cpu().numpy()
+    assert np.array_equal(idx, oracle_mod.knn_expanded(x.numpy(), 5))
+
+
 @pytest.mark.parametrize('kernel', [1, 2])
 def test_knn_mfma_adversarial_orders(cuda, oracle_mod, kernel):
     """Candidate orders that stress the selection: distances descending along the index (every candidate displaces an
