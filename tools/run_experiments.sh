@@ -16,4 +16,9 @@ PCC_AM_NORESIDENT=1 run python3 tools/time_fine.py 8
 run python3 tools/time_graph_bwd.py
 PCC_EDGE_SCATTER=1 run python3 tools/time_graph_bwd.py
 run python3 tools/time_emd.py
+run ./tools/issue_bench
+run ./tools/mfma_coissue_bench
+run python3 tools/time_knn.py 1
+run python3 tools/ab_nn.py
+run python3 tools/host_enqueue.py
 tail -5 $O
