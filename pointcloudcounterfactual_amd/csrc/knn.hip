@@ -1,7 +1,7 @@
 // k-nearest-neighbour graph for gfx950 (MI355X), wave64.
 //
 // Replaces knn / pykeops_knn (reference src/utils/neighbour_ops.py:63-82: a PyKeOps argKmin over a lazy
-// (B,N,N) squared-distance tensor) -- PyKeOps has no ROCm backend.  Three kernels:
+// (B,N,N) squared-distance tensor) -- PyKeOps has no ROCm backend.  Four kernels:
 //   * knn_sorted_kernel (c <= 3, n <= 16384): exact difference-form distances on the f32 VALU, the formula the GPU
 //     reference evaluates (pykeops_square_distance, :35-40), on the Hilbert-sorted cloud: only the candidate boxes
 //     that can still hold one of a query's k nearest are visited (see the kernel).
@@ -15,6 +15,8 @@
 //     The 32x32 accumulator tile is oriented with the QUERY on the lane (column) and 16 candidates in
 //     the lane's accumulator registers, so the same per-lane top-K consumes distances straight from
 //     registers: the (B,N,N) distance matrix never exists in memory.
+//   * knn_mfma_split_kernel (c >= 4, launches that fill the chip): the same arithmetic with the matrix waves and the
+//     selection waves of a workgroup apart, one query per selection lane (see the kernel).
 #include "pcc_common.hpp"
 #include "pcc_neighbour.h"
 #include "pcc_test_hooks.h"
